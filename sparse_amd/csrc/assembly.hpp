@@ -1,0 +1,314 @@
+// assembly.hpp -- COO -> CSR record (sr.sparse / sc.sparse, compressed.fut:154-160,
+// :211-212, norm_coo :72-87) and everything that re-enters it (+, -, physical
+// CSR<->CSC conversion), plus the nnz-balanced tiling ("plan") of a record.
+//
+// Pipeline (all on the context stream):
+//   pack      (row, col) i64 pair -> one unsigned key (row << cbits | col), bounds
+//             check (the assert at :156) folded in                         [1 pass]
+//   sort      stable LSD radix sort on the significant key bits only, payload =
+//             source index (radix_sort.hpp)                        [<= 8 passes]
+//   heads     inclusive scan of the head flags key[i] != key[i-1] (:77-81) gives
+//             every run its output slot; the scan total is the merged count
+//   emit      one thread per element: run heads fold their run left to right in
+//             sorted (= input) order (segmented_reduce :83-84) and write
+//             col_idx/vals; the last element of each row writes
+//             row_ptr[row+1] = slots so far
+//   rowptr    inclusive max-scan over row_ptr fills empty rows.  Result equals
+//             reduce_by_index + scan (:158-159): row_ptr[r+1] = #entries in
+//             rows 0..r = row_off[r].
+#pragma once
+
+#include "radix_sort.hpp"
+
+namespace samd {
+
+template <class K>
+__device__ __forceinline__ K shl_safe(K v, int s) { return s >= (int)(sizeof(K) * 8) ? (K)0 : (K)(v << s); }
+template <class K>
+__device__ __forceinline__ K shr_safe(K v, int s) { return s >= (int)(sizeof(K) * 8) ? (K)0 : (K)(v >> s); }
+
+// ---------------------------------------------------------------- pack kernels
+template <class K>
+__global__ __launch_bounds__(kBlock) void pack_coo_kernel(const int64_t *__restrict__ major,
+                                                          const int64_t *__restrict__ minor, int64_t count,
+                                                          int64_t n_major, int64_t n_minor, int minor_bits,
+                                                          K *__restrict__ keys, int *__restrict__ err) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const int64_t r = major[i], c = minor[i];
+  K k = 0;
+  if (r < 0 || r >= n_major || c < 0 || c >= n_minor) *err = 1;
+  else k = shl_safe<K>((K)r, minor_bits) | (K)c;
+  keys[i] = k;
+}
+
+// Row that stores entry e of a record, searched only inside e's tile
+// (tile_lb brackets the candidates, so the search is a handful of steps in
+// cache-resident data instead of log2(n) over all of row_ptr).
+__device__ __forceinline__ int64_t find_row(const int64_t *__restrict__ row_ptr, const int64_t *__restrict__ tile_lb,
+                                            int64_t tile, int64_t e) {
+  const int64_t t = e / tile;
+  int64_t lo = tile_lb[t] > 0 ? tile_lb[t] - 1 : 0;
+  int64_t hi = tile_lb[t + 1];  // rows >= hi start beyond this tile
+  // largest r in [lo, hi) with row_ptr[r] <= e
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (row_ptr[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// key of stored entry e: (row << minor_bits | col), or swapped (col << minor_bits | row)
+template <class K, class I, bool SWAP>
+__global__ __launch_bounds__(kBlock) void pack_csr_kernel(const int64_t *__restrict__ row_ptr,
+                                                          const I *__restrict__ col, int64_t nnz,
+                                                          const int64_t *__restrict__ tile_lb, int64_t tile,
+                                                          int minor_bits, K *__restrict__ keys) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nnz) return;
+  const K r = (K)find_row(row_ptr, tile_lb, tile, e);
+  const K c = (K)col[e];
+  keys[e] = SWAP ? (shl_safe<K>(c, minor_bits) | r) : (shl_safe<K>(r, minor_bits) | c);
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void concat_vals_kernel(const T *__restrict__ a, int64_t na,
+                                                             const T *__restrict__ b, int64_t nb, bool negate_b,
+                                                             T *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < na) out[i] = a[i];
+  else if (i < na + nb) out[i] = negate_b ? (T)((T)(-1) * b[i - na]) : b[i - na];  // scale (T.i64 (-1)), :183
+}
+
+// ---------------------------------------------------------------- merge / emit
+template <class K>
+struct HeadFlagIn {
+  const K *keys;
+  __device__ __forceinline__ uint32_t operator()(int64_t i) const {
+    return (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+  }
+};
+
+template <class K, class T, class I>
+__global__ __launch_bounds__(kBlock) void merge_emit_kernel(const K *__restrict__ keys,
+                                                            const uint32_t *__restrict__ perm,
+                                                            const uint32_t *__restrict__ slot,  // inclusive head count
+                                                            const T *__restrict__ vals_in, int64_t count,
+                                                            int minor_bits, K minor_mask, I *__restrict__ col_out,
+                                                            T *__restrict__ vals_out, int64_t *__restrict__ row_ptr) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const K k = keys[i];
+  const bool head = (i == 0) || keys[i - 1] != k;
+  const uint32_t s = slot[i];
+  const bool has_next = i + 1 < count;
+  const K knext = has_next ? keys[i + 1] : (K)0;
+  if (head) {
+    T acc = vals_in[perm[i]];
+    if (has_next && knext == k) {
+      for (int64_t j = i + 1; j < count && keys[j] == k; j++) acc = (T)(acc + vals_in[perm[j]]);
+    }
+    col_out[s - 1] = (I)(k & minor_mask);
+    vals_out[s - 1] = acc;
+  }
+  const K major = shr_safe<K>(k, minor_bits);
+  if (!has_next || shr_safe<K>(knext, minor_bits) != major) row_ptr[(int64_t)major + 1] = (int64_t)s;
+}
+
+// ---------------------------------------------------------------------- plan
+__global__ __launch_bounds__(kBlock) void plan_kernel(const int64_t *__restrict__ row_ptr, int64_t n, int64_t tile,
+                                                      int64_t ntiles, int64_t *__restrict__ tile_lb) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t > ntiles) return;
+  if (t == ntiles) { tile_lb[t] = n; return; }
+  const int64_t target = t * tile;
+  int64_t lo = 0, hi = n;  // first r in [0,n) with row_ptr[r] >= target, else n
+  while (lo < hi) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (row_ptr[mid] >= target) hi = mid; else lo = mid + 1;
+  }
+  tile_lb[t] = lo;
+}
+
+constexpr int64_t kPlanTile = 2048;  // entries per tile; matches the SpMV kernels' TILE
+
+template <class T>
+int build_plan(futhark_context *ctx, CsrBody<T> *b) {
+  b->tile = kPlanTile;
+  b->ntiles = cdiv(b->nnz, b->tile);
+  SAMD_TRY(dalloc(ctx, &b->tile_lb, b->ntiles + 1));
+  SAMD_TRY(dalloc(ctx, &b->head, b->ntiles));
+  hipLaunchKernelGGL(plan_kernel, dim3((unsigned)cdiv(b->ntiles + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     (const int64_t *)b->row_ptr, b->n, b->tile, b->ntiles, b->tile_lb);
+  SAMD_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+inline bool use_col32(futhark_context *ctx, int64_t m) { return !ctx->opt_wide_col && m <= 0x7fffffffLL; }
+
+// ------------------------------------------------------------------- the core
+// keys: count packed keys (device, consumed as scratch).  Sort covers key bits
+// [begin_bit, end_bit); bits below begin_bit must already be in order within
+// equal upper bits (the CSR->CSC conversion uses that).  err_flag (device int,
+// may be null) is checked at the one host synchronisation point.
+template <class K, class T>
+int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_bit, int end_bit, int minor_bits,
+                  const T *vals_in, int64_t n_major, int64_t n_minor, const int *err_flag, CsrBody<T> **out) {
+  CsrBody<T> *b = new CsrBody<T>();
+  CsrGuard<T> guard(ctx, b);
+  b->n = n_major;
+  b->m = n_minor;
+  SAMD_TRY(dalloc(ctx, &b->row_ptr, n_major + 1));
+  SAMD_HIP(ctx, hipMemsetAsync(b->row_ptr, 0, sizeof(int64_t) * (size_t)(n_major + 1), ctx->stream));
+
+  int64_t merged = 0;
+  if (count > 0) {
+    Tmp<K> keys_b(ctx);
+    Tmp<uint32_t> pay_a(ctx), pay_b(ctx), slot(ctx);
+    SAMD_TRY(keys_b.get(count));
+    SAMD_TRY(pay_a.get(count));
+    SAMD_TRY(pay_b.get(count));
+    K *ks = nullptr;
+    uint32_t *perm = nullptr;
+    SAMD_TRY(radix_sort_pairs<K>(ctx, keys.p, keys_b.p, pay_a.p, pay_b.p, count, begin_bit, end_bit, &ks, &perm));
+
+    // head flags -> slots; total -> host (the only synchronisation of an assembly)
+    uint32_t *slots = (perm == pay_a.p) ? pay_b.p : pay_a.p;  // the payload buffer not holding perm
+    SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t) * 2, ctx->stream));
+    SAMD_TRY((device_scan<uint32_t, OpAdd, HeadFlagIn<K>, false>(ctx, HeadFlagIn<K>{ks}, count, 0u, OpAdd(), slots,
+                                                                  (uint32_t *)ctx->d_small)));
+    if (err_flag)
+      SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 1, err_flag, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    int64_t host[2];
+    SAMD_TRY(read_small(ctx, ctx->d_small, 2, host));
+    if ((int)(host[1] & 0xffffffff) != 0)
+      return set_error(ctx, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
+    merged = (int64_t)(uint32_t)(host[0] & 0xffffffffLL);
+
+    b->nnz = merged;
+    SAMD_TRY(dalloc(ctx, &b->vals, merged));
+    const K minor_mask = minor_bits >= (int)(sizeof(K) * 8) ? (K)~(K)0 : (K)(((K)1 << minor_bits) - 1);
+    const unsigned grid = (unsigned)cdiv(count, kBlock);
+    if (use_col32(ctx, n_minor)) {
+      SAMD_TRY(dalloc(ctx, &b->col32, merged));
+      hipLaunchKernelGGL((merge_emit_kernel<K, T, int32_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const K *)ks,
+                         (const uint32_t *)perm, (const uint32_t *)slots, vals_in, count, minor_bits, minor_mask,
+                         b->col32, b->vals, b->row_ptr);
+    } else {
+      SAMD_TRY(dalloc(ctx, &b->col64, merged));
+      hipLaunchKernelGGL((merge_emit_kernel<K, T, int64_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const K *)ks,
+                         (const uint32_t *)perm, (const uint32_t *)slots, vals_in, count, minor_bits, minor_mask,
+                         b->col64, b->vals, b->row_ptr);
+    }
+    SAMD_LAUNCH_CHECK(ctx);
+    if (n_major > 0)
+      SAMD_TRY((device_scan<int64_t, OpMax, PtrIn<int64_t>, false>(ctx, PtrIn<int64_t>{b->row_ptr + 1}, n_major,
+                                                                    (int64_t)0, OpMax(), b->row_ptr + 1,
+                                                                    (int64_t *)nullptr)));
+  } else {
+    if (err_flag) {  // nothing to check, nothing stored
+    }
+    SAMD_TRY(dalloc(ctx, &b->vals, 0));
+    if (use_col32(ctx, n_minor)) SAMD_TRY(dalloc(ctx, &b->col32, 0));
+    else SAMD_TRY(dalloc(ctx, &b->col64, 0));
+  }
+  SAMD_TRY(build_plan(ctx, b));
+  *out = guard.release();
+  return 0;
+}
+
+// sr.sparse n_major n_minor (zip3 major minor vals)
+template <class T>
+int assemble_coo(futhark_context *ctx, int64_t n_major, int64_t n_minor, const int64_t *major, const int64_t *minor,
+                 const T *vals, int64_t count, CsrBody<T> **out) {
+  if (n_major < 0 || n_minor < 0) return set_error(ctx, "sparse: negative dimension");
+  const int rbits = bits_for(n_major), cbits = bits_for(n_minor);
+  if (rbits + cbits > 64) return set_error(ctx, "sparse: n*m exceeds 2^64 key space");
+  Tmp<int> err(ctx);
+  SAMD_TRY(err.get(1));
+  SAMD_HIP(ctx, hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
+  const unsigned grid = (unsigned)cdiv(count > 0 ? count : 1, kBlock);
+  if (rbits + cbits <= 32) {
+    Tmp<uint32_t> keys(ctx);
+    SAMD_TRY(keys.get(count));
+    if (count > 0) {
+      hipLaunchKernelGGL((pack_coo_kernel<uint32_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, major, minor, count,
+                         n_major, n_minor, cbits, keys.p, err.p);
+      SAMD_LAUNCH_CHECK(ctx);
+    }
+    return assemble_core<uint32_t, T>(ctx, keys, count, 0, rbits + cbits, cbits, vals, n_major, n_minor, err.p, out);
+  }
+  Tmp<uint64_t> keys(ctx);
+  SAMD_TRY(keys.get(count));
+  if (count > 0) {
+    hipLaunchKernelGGL((pack_coo_kernel<uint64_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, major, minor, count,
+                       n_major, n_minor, cbits, keys.p, err.p);
+    SAMD_LAUNCH_CHECK(ctx);
+  }
+  return assemble_core<uint64_t, T>(ctx, keys, count, 0, rbits + cbits, cbits, vals, n_major, n_minor, err.p, out);
+}
+
+template <class K, class T, bool SWAP>
+int pack_csr(futhark_context *ctx, const CsrBody<T> *a, int minor_bits, K *keys) {
+  if (a->nnz == 0) return 0;
+  const unsigned grid = (unsigned)cdiv(a->nnz, kBlock);
+  if (a->col32)
+    hipLaunchKernelGGL((pack_csr_kernel<K, int32_t, SWAP>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                       (const int64_t *)a->row_ptr, (const int32_t *)a->col32, a->nnz, (const int64_t *)a->tile_lb,
+                       a->tile, minor_bits, keys);
+  else
+    hipLaunchKernelGGL((pack_csr_kernel<K, int64_t, SWAP>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                       (const int64_t *)a->row_ptr, (const int64_t *)a->col64, a->nnz, (const int64_t *)a->tile_lb,
+                       a->tile, minor_bits, keys);
+  SAMD_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+// Physical conversion: record of A (n x m) -> record of A^T (m x n)
+// = sr.sparse m n (map swap (sr.coo A))  (compressed.fut:166-177, :211-212).
+// Stored entries are already (row, col)-sorted, so a stable sort on the column
+// bits alone reproduces the full (col, row) order; nothing can merge.
+template <class T>
+int transpose_physical(futhark_context *ctx, const CsrBody<T> *a, CsrBody<T> **out) {
+  const int rbits = bits_for(a->n), cbits = bits_for(a->m);
+  if (rbits + cbits <= 32) {
+    Tmp<uint32_t> keys(ctx);
+    SAMD_TRY(keys.get(a->nnz));
+    SAMD_TRY((pack_csr<uint32_t, T, true>(ctx, a, rbits, keys.p)));
+    return assemble_core<uint32_t, T>(ctx, keys, a->nnz, rbits, rbits + cbits, rbits, a->vals, a->m, a->n, nullptr,
+                                      out);
+  }
+  Tmp<uint64_t> keys(ctx);
+  SAMD_TRY(keys.get(a->nnz));
+  SAMD_TRY((pack_csr<uint64_t, T, true>(ctx, a, rbits, keys.p)));
+  return assemble_core<uint64_t, T>(ctx, keys, a->nnz, rbits, rbits + cbits, rbits, a->vals, a->m, a->n, nullptr, out);
+}
+
+// sr.+ / sr.- : (coo a ++ coo (scale -1 b)) |> sparse n m  (compressed.fut:179-183)
+template <class T>
+int add_sub(futhark_context *ctx, const CsrBody<T> *a, const CsrBody<T> *b, bool sub, CsrBody<T> **out) {
+  if (a->n != b->n || a->m != b->m) return set_error(ctx, "add/sub: shape mismatch");
+  const int64_t tot = a->nnz + b->nnz;
+  const int rbits = bits_for(a->n), cbits = bits_for(a->m);
+  Tmp<T> vals(ctx);
+  SAMD_TRY(vals.get(tot));
+  if (tot > 0) {
+    hipLaunchKernelGGL((concat_vals_kernel<T>), dim3((unsigned)cdiv(tot, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const T *)a->vals, a->nnz, (const T *)b->vals, b->nnz, sub, vals.p);
+    SAMD_LAUNCH_CHECK(ctx);
+  }
+  if (rbits + cbits <= 32) {
+    Tmp<uint32_t> keys(ctx);
+    SAMD_TRY(keys.get(tot));
+    SAMD_TRY((pack_csr<uint32_t, T, false>(ctx, a, cbits, keys.p)));
+    SAMD_TRY((pack_csr<uint32_t, T, false>(ctx, b, cbits, keys.p + a->nnz)));
+    return assemble_core<uint32_t, T>(ctx, keys, tot, 0, rbits + cbits, cbits, vals.p, a->n, a->m, nullptr, out);
+  }
+  Tmp<uint64_t> keys(ctx);
+  SAMD_TRY(keys.get(tot));
+  SAMD_TRY((pack_csr<uint64_t, T, false>(ctx, a, cbits, keys.p)));
+  SAMD_TRY((pack_csr<uint64_t, T, false>(ctx, b, cbits, keys.p + a->nnz)));
+  return assemble_core<uint64_t, T>(ctx, keys, tot, 0, rbits + cbits, cbits, vals.p, a->n, a->m, nullptr, out);
+}
+
+}  // namespace samd

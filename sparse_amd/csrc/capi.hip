@@ -1,0 +1,779 @@
+// capi.hip -- the extern "C" boundary declared in include/sparse_amd.h.
+//
+// Every function: lock the context, make its device current, run stream-ordered
+// work, return 0 / non-zero with the message left for futhark_context_get_error.
+#include "common.hpp"
+#include "scan.hpp"
+#include "radix_sort.hpp"
+#include "assembly.hpp"
+#include "spmv.hpp"
+#include "spmm.hpp"
+#include "convert.hpp"
+
+using namespace samd;
+
+// ---------------------------------------------------------------- records
+struct futhark_i64_1d : DevArray<int64_t, 1> {};
+struct futhark_i32_1d : DevArray<int32_t, 1> {};
+struct futhark_f32_1d : DevArray<float, 1> {};
+struct futhark_f64_1d : DevArray<double, 1> {};
+struct futhark_i32_2d : DevArray<int32_t, 2> {};
+struct futhark_f32_2d : DevArray<float, 2> {};
+struct futhark_f64_2d : DevArray<double, 2> {};
+
+struct futhark_opaque_csr_f64 { CsrBody<double> *b; };
+struct futhark_opaque_csc_f64 { CsrBody<double> *b; };
+struct futhark_opaque_csr_f32 { CsrBody<float> *b; };
+struct futhark_opaque_csc_f32 { CsrBody<float> *b; };
+struct futhark_opaque_csr_i32 { CsrBody<int32_t> *b; };
+struct futhark_opaque_csc_i32 { CsrBody<int32_t> *b; };
+
+namespace {
+
+struct Enter {
+  std::lock_guard<std::mutex> g;
+  bool ok;
+  explicit Enter(futhark_context *ctx) : g(ctx->mu), ok(ctx->own_stream != nullptr) {
+    if (ok) (void)hipSetDevice(ctx->device);
+    ctx->n_entries++;
+  }
+};
+
+// A context whose device could not be opened fails every call loudly: there is
+// no CPU path behind this boundary.
+struct NoDevice {
+  futhark_context *ctx;
+  operator int() const {
+    if (!ctx->has_err) set_error(ctx, "context has no usable HIP device; libsparse_amd has no CPU path");
+    return 1;
+  }
+  template <class P>
+  operator P *() const {
+    if (!ctx->has_err) set_error(ctx, "context has no usable HIP device; libsparse_amd has no CPU path");
+    return nullptr;
+  }
+};
+#define ENTER(ctx) \
+  Enter g(ctx);    \
+  if (!g.ok) return NoDevice{ctx}
+
+template <class A>
+int arr_alloc(futhark_context *ctx, A **out, const int64_t *shape, int rank) {
+  A *a = new A();
+  int64_t count = 1;
+  for (int i = 0; i < rank; i++) {
+    if (shape[i] < 0) { delete a; return set_error(ctx, "negative array dimension"); }
+    a->shape[i] = shape[i];
+    count *= shape[i];
+  }
+  a->owned = true;
+  if (dalloc(ctx, &a->data, count) != 0) { delete a; return 1; }
+  *out = a;
+  return 0;
+}
+
+template <class A>
+int arr_free(futhark_context *ctx, A *a) {
+  if (!a) return 0;
+  if (a->owned) dfree(ctx, a->data);
+  delete a;
+  return 0;
+}
+
+template <class A, class T>
+A *arr_new(futhark_context *ctx, const T *host, const int64_t *shape, int rank, hipMemcpyKind kind) {
+  A *a = nullptr;
+  if (arr_alloc(ctx, &a, shape, rank) != 0) return nullptr;
+  const int64_t count = a->count();
+  if (count > 0) {
+    hipError_t e = hipMemcpyAsync(a->data, host, sizeof(T) * (size_t)count, kind, ctx->stream);
+    if (e == hipSuccess && kind == hipMemcpyHostToDevice) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error(ctx, "copy into new array failed: %s", hipGetErrorString(e));
+      arr_free(ctx, a);
+      return nullptr;
+    }
+  }
+  return a;
+}
+
+template <class A>
+A *arr_wrap(futhark_context *ctx, void *dev, const int64_t *shape, int rank) {
+  (void)ctx;
+  A *a = new A();
+  for (int i = 0; i < rank; i++) a->shape[i] = shape[i];
+  a->data = (decltype(a->data))dev;
+  a->owned = false;
+  return a;
+}
+
+template <class A, class T>
+int arr_values(futhark_context *ctx, A *a, T *host) {
+  const int64_t count = a->count();
+  if (count > 0) SAMD_HIP(ctx, hipMemcpyAsync(host, a->data, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+template <class H, class T>
+int wrap_body(futhark_context *ctx, H **out, CsrBody<T> *b) {
+  (void)ctx;
+  H *h = new H();
+  h->b = b;
+  *out = h;
+  return 0;
+}
+
+template <class H>
+int free_handle(futhark_context *ctx, H *h) {
+  if (!h) return 0;
+  csr_release(ctx, h->b);
+  delete h;
+  return 0;
+}
+
+// ---- typed entry bodies (TT-independent logic; the macros below only name them)
+template <class T, class H, class VA>
+int e_sparse(futhark_context *ctx, H **out, int64_t n_major, int64_t n_minor, const futhark_i64_1d *major,
+             const futhark_i64_1d *minor, const VA *vs) {
+  if (major->shape[0] != minor->shape[0] || major->shape[0] != vs->shape[0])
+    return set_error(ctx, "sparse: coordinate arrays differ in length");
+  CsrBody<T> *b = nullptr;
+  SAMD_TRY(assemble_coo<T>(ctx, n_major, n_minor, major->data, minor->data, vs->data, major->shape[0], &b));
+  return wrap_body(ctx, out, b);
+}
+
+template <class T, class H>
+int e_eye(futhark_context *ctx, H **out, int64_t n, int64_t m) {
+  CsrBody<T> *b = nullptr;
+  SAMD_TRY(make_eye<T>(ctx, n, m, nullptr, &b));
+  return wrap_body(ctx, out, b);
+}
+
+template <class T, class H>
+int e_zero(futhark_context *ctx, H **out, int64_t n, int64_t m) {
+  CsrBody<T> *b = nullptr;
+  SAMD_TRY(make_zero<T>(ctx, n, m, &b));
+  return wrap_body(ctx, out, b);
+}
+
+template <class T, class H, class VA>
+int e_diag(futhark_context *ctx, H **out, const VA *v) {
+  CsrBody<T> *b = nullptr;
+  SAMD_TRY(make_eye<T>(ctx, v->shape[0], v->shape[0], v->data, &b));
+  return wrap_body(ctx, out, b);
+}
+
+template <class T, class H, class A2>
+int e_dense(futhark_context *ctx, A2 **out, const H *a, bool is_csc) {
+  // a csc handle stores the transposed record; its dense is [stored m][stored n]
+  const int64_t shape[2] = {is_csc ? a->b->m : a->b->n, is_csc ? a->b->n : a->b->m};
+  A2 *o = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &o, shape, 2));
+  if (to_dense<T>(ctx, a->b, is_csc, o->data) != 0) { arr_free(ctx, o); return 1; }
+  *out = o;
+  return 0;
+}
+
+template <class T, class H>
+int e_scale(futhark_context *ctx, H **out, T v, const H *a) {
+  CsrBody<T> *b = nullptr;
+  SAMD_TRY(make_scaled<T>(ctx, v, a->b, &b));
+  return wrap_body(ctx, out, b);
+}
+
+template <class T, class H, class VA>
+int e_coo(futhark_context *ctx, futhark_i64_1d **o0, futhark_i64_1d **o1, VA **o2, const H *a, bool is_csc) {
+  const int64_t shape[1] = {a->b->nnz};
+  futhark_i64_1d *r = nullptr, *c = nullptr;
+  VA *v = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &r, shape, 1));
+  if (arr_alloc(ctx, &c, shape, 1) != 0) { arr_free(ctx, r); return 1; }
+  if (arr_alloc(ctx, &v, shape, 1) != 0) { arr_free(ctx, r); arr_free(ctx, c); return 1; }
+  if (to_coo<T>(ctx, a->b, r->data, c->data, v->data) != 0) {
+    arr_free(ctx, r); arr_free(ctx, c); arr_free(ctx, v);
+    return 1;
+  }
+  // sc.coo = sr.coo |> map swap (compressed.fut:208-209): free in SoA, swap the handles
+  *o0 = is_csc ? c : r;
+  *o1 = is_csc ? r : c;
+  *o2 = v;
+  return 0;
+}
+
+template <class T, class H>
+int e_addsub(futhark_context *ctx, H **out, const H *a, const H *b, bool sub) {
+  CsrBody<T> *r = nullptr;
+  SAMD_TRY(add_sub<T>(ctx, a->b, b->b, sub, &r));
+  return wrap_body(ctx, out, r);
+}
+
+template <class HO, class HI>
+int e_relabel(futhark_context *ctx, HO **out, const HI *a) {
+  a->b->refs++;
+  return wrap_body(ctx, out, a->b);
+}
+
+template <class T, class H, class VA>
+int e_smvm(futhark_context *ctx, VA **out, const H *a, const VA *x) {
+  if (x->shape[0] != a->b->m) return set_error(ctx, "smvm: vector length %lld does not match matrix (%lld)",
+                                               (long long)x->shape[0], (long long)a->b->m);
+  const int64_t shape[1] = {a->b->n};
+  VA *y = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &y, shape, 1));
+  if (spmv<T>(ctx, a->b, x->data, y->data) != 0) { arr_free(ctx, y); return 1; }
+  *out = y;
+  return 0;
+}
+
+template <class T, class H, class A2>
+int e_smm(futhark_context *ctx, A2 **out, const H *a, const A2 *B) {
+  if (B->shape[0] != a->b->m) return set_error(ctx, "smm: panel has %lld rows, matrix has %lld columns",
+                                               (long long)B->shape[0], (long long)a->b->m);
+  const int64_t shape[2] = {a->b->n, B->shape[1]};
+  A2 *C = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &C, shape, 2));
+  if (spmm<T>(ctx, a->b, B->data, B->shape[1], C->data) != 0) { arr_free(ctx, C); return 1; }
+  *out = C;
+  return 0;
+}
+
+template <class T, class HO, class HI>
+int e_convert(futhark_context *ctx, HO **out, const HI *a) {
+  CsrBody<T> *b = nullptr;
+  SAMD_TRY(transpose_physical<T>(ctx, a->b, &b));
+  return wrap_body(ctx, out, b);
+}
+
+template <class T, class HR, class HC>
+int e_smsmm(futhark_context *ctx, HR **out, const HR *a, const HC *b) {
+  CsrBody<T> *r = nullptr;
+  SAMD_TRY(smsmm<T>(ctx, a->b, b->b, &r));
+  return wrap_body(ctx, out, r);
+}
+
+template <class T, class H, class VA>
+int e_fields(futhark_context *ctx, futhark_i64_1d **ro, futhark_i64_1d **ci, VA **va, const H *a) {
+  const int64_t sn[1] = {a->b->n}, sz[1] = {a->b->nnz};
+  futhark_i64_1d *r = nullptr, *c = nullptr;
+  VA *v = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &r, sn, 1));
+  if (arr_alloc(ctx, &c, sz, 1) != 0) { arr_free(ctx, r); return 1; }
+  if (arr_alloc(ctx, &v, sz, 1) != 0) { arr_free(ctx, r); arr_free(ctx, c); return 1; }
+  if (to_fields<T>(ctx, a->b, r->data, c->data, v->data) != 0) {
+    arr_free(ctx, r); arr_free(ctx, c); arr_free(ctx, v);
+    return 1;
+  }
+  *ro = r; *ci = c; *va = v;
+  return 0;
+}
+
+template <class T, class H, class VA>
+int e_from_fields(futhark_context *ctx, H **out, int64_t n, int64_t m, const futhark_i64_1d *ro,
+                  const futhark_i64_1d *ci, const VA *va) {
+  if (ro->shape[0] != n) return set_error(ctx, "from_fields: row_off must have length n");
+  if (ci->shape[0] != va->shape[0]) return set_error(ctx, "from_fields: col_idx and vals differ in length");
+  CsrBody<T> *b = nullptr;
+  SAMD_TRY(from_fields<T>(ctx, n, m, ro->data, ci->data, va->data, ci->shape[0], &b));
+  return wrap_body(ctx, out, b);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ context
+struct futhark_context_config *futhark_context_config_new(void) { return new futhark_context_config(); }
+void futhark_context_config_free(struct futhark_context_config *cfg) { delete cfg; }
+void futhark_context_config_set_debugging(struct futhark_context_config *cfg, int flag) { cfg->debugging = flag; }
+void futhark_context_config_set_profiling(struct futhark_context_config *cfg, int flag) { cfg->profiling = flag; }
+void futhark_context_config_set_logging(struct futhark_context_config *cfg, int flag) { cfg->logging = flag; }
+void futhark_context_config_set_device(struct futhark_context_config *cfg, const char *s) {
+  if (!s) return;
+  if (s[0] == '#') s++;
+  cfg->device = atoi(s);
+}
+
+struct futhark_context *futhark_context_new(struct futhark_context_config *cfg) {
+  futhark_context *ctx = new futhark_context();
+  ctx->device = cfg ? cfg->device : 0;
+  ctx->logging = cfg ? cfg->logging : 0;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    set_error(ctx, "no HIP device available (%s); libsparse_amd has no CPU path",
+              e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return ctx;  // futhark convention: a context is always returned; the error is pending
+  }
+  if (ctx->device < 0 || ctx->device >= ndev) {
+    set_error(ctx, "device #%d out of range (%d present)", ctx->device, ndev);
+    return ctx;
+  }
+  hipDeviceProp_t prop;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_small, sizeof(int64_t) * 16, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_small, sizeof(int64_t) * 16) != hipSuccess) {
+    set_error(ctx, "context initialisation failed: %s", hipGetErrorString(hipGetLastError()));
+    return ctx;
+  }
+  ctx->stream = ctx->own_stream;
+  ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (ctx->logging) fprintf(stderr, "[sparse_amd] device #%d %s (%s), %d CUs\n", ctx->device, prop.name,
+                            prop.gcnArchName, ctx->num_cu);
+  return ctx;
+}
+
+void futhark_context_free(struct futhark_context *ctx) {
+  if (!ctx) return;
+  if (ctx->own_stream) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->pool.clear();
+    (void)hipFree(ctx->d_small);
+    (void)hipHostFree(ctx->h_small);
+    (void)hipStreamDestroy(ctx->own_stream);
+  }
+  delete ctx;
+}
+
+int futhark_context_sync(struct futhark_context *ctx) {
+  ENTER(ctx);
+  if (ctx->has_err) return 1;
+  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+char *futhark_context_get_error(struct futhark_context *ctx) {
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (!ctx->has_err) return nullptr;
+  char *s = strdup(ctx->err.c_str());
+  ctx->has_err = false;
+  ctx->err.clear();
+  return s;
+}
+
+int futhark_context_clear_caches(struct futhark_context *ctx) {
+  ENTER(ctx);
+  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->pool.clear();
+  return 0;
+}
+
+char *futhark_context_report(struct futhark_context *ctx) {
+  std::lock_guard<std::mutex> g(ctx->mu);
+  char buf[512];
+  snprintf(buf, sizeof buf,
+           "device: #%d (%d CUs)\nAPI calls: %lld\ndevice memory held: %zu bytes (peak %zu, cached %zu, live blocks %zu)\n",
+           ctx->device, ctx->num_cu, (long long)ctx->n_entries, ctx->pool.total(), ctx->pool.peak(),
+           ctx->pool.cached(), ctx->pool.live_blocks());
+  return strdup(buf);
+}
+
+int sparse_amd_context_set_stream(struct futhark_context *ctx, void *hip_stream) {
+  ENTER(ctx);
+  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return 0;
+}
+void *sparse_amd_context_get_stream(struct futhark_context *ctx) { return (void *)ctx->stream; }
+
+int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, int64_t value) {
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (!strcmp(key, "spmv_algo")) ctx->opt_spmv_algo = value;
+  else if (!strcmp(key, "spmv_lanes")) ctx->opt_spmv_lanes = value;
+  else if (!strcmp(key, "wide_col")) ctx->opt_wide_col = value;
+  else return set_error(ctx, "unknown option '%s'", key);
+  return 0;
+}
+int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *key) {
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (!strcmp(key, "spmv_algo")) return ctx->opt_spmv_algo;
+  if (!strcmp(key, "spmv_lanes")) return ctx->opt_spmv_lanes;
+  if (!strcmp(key, "wide_col")) return ctx->opt_wide_col;
+  if (!strcmp(key, "num_cu")) return ctx->num_cu;
+  return -1;
+}
+const char *sparse_amd_version(void) { return "sparse_amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------- arrays
+#define SAMD_ARRAY_1D(NAME, CT)                                                                              \
+  struct futhark_##NAME##_1d *futhark_new_##NAME##_1d(struct futhark_context *ctx, const CT *data, int64_t d0) { \
+    ENTER(ctx);                                                                                            \
+    const int64_t shape[1] = {d0};                                                                           \
+    return arr_new<futhark_##NAME##_1d, CT>(ctx, data, shape, 1, hipMemcpyHostToDevice);                     \
+  }                                                                                                          \
+  struct futhark_##NAME##_1d *futhark_new_raw_##NAME##_1d(struct futhark_context *ctx, const void *data,     \
+                                                          int64_t d0) {                                      \
+    ENTER(ctx);                                                                                            \
+    const int64_t shape[1] = {d0};                                                                           \
+    return arr_new<futhark_##NAME##_1d, CT>(ctx, (const CT *)data, shape, 1, hipMemcpyDeviceToDevice);       \
+  }                                                                                                          \
+  struct futhark_##NAME##_1d *sparse_amd_wrap_##NAME##_1d(struct futhark_context *ctx, void *data, int64_t d0) { \
+    ENTER(ctx);                                                                                            \
+    const int64_t shape[1] = {d0};                                                                           \
+    return arr_wrap<futhark_##NAME##_1d>(ctx, data, shape, 1);                                               \
+  }                                                                                                          \
+  int futhark_free_##NAME##_1d(struct futhark_context *ctx, struct futhark_##NAME##_1d *arr) {               \
+    ENTER(ctx);                                                                                            \
+    return arr_free(ctx, arr);                                                                               \
+  }                                                                                                          \
+  int futhark_values_##NAME##_1d(struct futhark_context *ctx, struct futhark_##NAME##_1d *arr, CT *data) {   \
+    ENTER(ctx);                                                                                            \
+    return arr_values(ctx, arr, data);                                                                       \
+  }                                                                                                          \
+  void *futhark_values_raw_##NAME##_1d(struct futhark_context *ctx, struct futhark_##NAME##_1d *arr) {       \
+    (void)ctx;                                                                                               \
+    return (void *)arr->data;                                                                                \
+  }                                                                                                          \
+  const int64_t *futhark_shape_##NAME##_1d(struct futhark_context *ctx, struct futhark_##NAME##_1d *arr) {   \
+    (void)ctx;                                                                                               \
+    return arr->shape;                                                                                       \
+  }
+
+#define SAMD_ARRAY_2D(NAME, CT)                                                                              \
+  struct futhark_##NAME##_2d *futhark_new_##NAME##_2d(struct futhark_context *ctx, const CT *data, int64_t d0, \
+                                                      int64_t d1) {                                          \
+    ENTER(ctx);                                                                                            \
+    const int64_t shape[2] = {d0, d1};                                                                       \
+    return arr_new<futhark_##NAME##_2d, CT>(ctx, data, shape, 2, hipMemcpyHostToDevice);                     \
+  }                                                                                                          \
+  struct futhark_##NAME##_2d *futhark_new_raw_##NAME##_2d(struct futhark_context *ctx, const void *data,     \
+                                                          int64_t d0, int64_t d1) {                          \
+    ENTER(ctx);                                                                                            \
+    const int64_t shape[2] = {d0, d1};                                                                       \
+    return arr_new<futhark_##NAME##_2d, CT>(ctx, (const CT *)data, shape, 2, hipMemcpyDeviceToDevice);       \
+  }                                                                                                          \
+  struct futhark_##NAME##_2d *sparse_amd_wrap_##NAME##_2d(struct futhark_context *ctx, void *data, int64_t d0, \
+                                                          int64_t d1) {                                      \
+    ENTER(ctx);                                                                                            \
+    const int64_t shape[2] = {d0, d1};                                                                       \
+    return arr_wrap<futhark_##NAME##_2d>(ctx, data, shape, 2);                                               \
+  }                                                                                                          \
+  int futhark_free_##NAME##_2d(struct futhark_context *ctx, struct futhark_##NAME##_2d *arr) {               \
+    ENTER(ctx);                                                                                            \
+    return arr_free(ctx, arr);                                                                               \
+  }                                                                                                          \
+  int futhark_values_##NAME##_2d(struct futhark_context *ctx, struct futhark_##NAME##_2d *arr, CT *data) {   \
+    ENTER(ctx);                                                                                            \
+    return arr_values(ctx, arr, data);                                                                       \
+  }                                                                                                          \
+  void *futhark_values_raw_##NAME##_2d(struct futhark_context *ctx, struct futhark_##NAME##_2d *arr) {       \
+    (void)ctx;                                                                                               \
+    return (void *)arr->data;                                                                                \
+  }                                                                                                          \
+  const int64_t *futhark_shape_##NAME##_2d(struct futhark_context *ctx, struct futhark_##NAME##_2d *arr) {   \
+    (void)ctx;                                                                                               \
+    return arr->shape;                                                                                       \
+  }
+
+SAMD_ARRAY_1D(i64, int64_t)
+SAMD_ARRAY_1D(i32, int32_t)
+SAMD_ARRAY_1D(f32, float)
+SAMD_ARRAY_1D(f64, double)
+SAMD_ARRAY_2D(i32, int32_t)
+SAMD_ARRAY_2D(f32, float)
+SAMD_ARRAY_2D(f64, double)
+
+// -------------------------------------------------------- typed matrix entries
+#define CSR(TT) struct futhark_opaque_csr_##TT
+#define CSC(TT) struct futhark_opaque_csc_##TT
+#define A1(TT) struct futhark_##TT##_1d
+#define A2(TT) struct futhark_##TT##_2d
+#define CTX struct futhark_context *ctx
+#define I64A const struct futhark_i64_1d
+
+#define SAMD_MATRIX(TT, CT)                                                                                   \
+  int futhark_free_opaque_csr_##TT(CTX, CSR(TT) * o) { ENTER(ctx); return free_handle(ctx, o); }            \
+  int futhark_free_opaque_csc_##TT(CTX, CSC(TT) * o) { ENTER(ctx); return free_handle(ctx, o); }            \
+  int futhark_entry_csr_##TT##_sparse(CTX, CSR(TT) * *out0, const int64_t n, const int64_t m, I64A *rs,       \
+                                      I64A *cs, const A1(TT) * vs) {                                          \
+    ENTER(ctx);                                                                                             \
+    return e_sparse<CT>(ctx, out0, n, m, rs, cs, vs);                                                         \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_sparse(CTX, CSC(TT) * *out0, const int64_t n, const int64_t m, I64A *rs,       \
+                                      I64A *cs, const A1(TT) * vs) {                                          \
+    ENTER(ctx); /* sr.sparse m n (swap coo) */                                                              \
+    return e_sparse<CT>(ctx, out0, m, n, cs, rs, vs);                                                         \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_zero(CTX, CSR(TT) * *out0, const int64_t n, const int64_t m) {                 \
+    ENTER(ctx);                                                                                             \
+    return e_zero<CT>(ctx, out0, n, m);                                                                       \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_zero(CTX, CSC(TT) * *out0, const int64_t n, const int64_t m) {                 \
+    ENTER(ctx);                                                                                             \
+    return e_zero<CT>(ctx, out0, m, n);                                                                       \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_eye(CTX, CSR(TT) * *out0, const int64_t n, const int64_t m) {                  \
+    ENTER(ctx);                                                                                             \
+    return e_eye<CT>(ctx, out0, n, m);                                                                        \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_eye(CTX, CSC(TT) * *out0, const int64_t n, const int64_t m) {                  \
+    ENTER(ctx);                                                                                             \
+    return e_eye<CT>(ctx, out0, m, n);                                                                        \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_diag(CTX, CSR(TT) * *out0, const A1(TT) * v) {                                 \
+    ENTER(ctx);                                                                                             \
+    return e_diag<CT>(ctx, out0, v);                                                                          \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_diag(CTX, CSC(TT) * *out0, const A1(TT) * v) {                                 \
+    ENTER(ctx);                                                                                             \
+    return e_diag<CT>(ctx, out0, v);                                                                          \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_dense(CTX, A2(TT) * *out0, const CSR(TT) * a) {                                \
+    ENTER(ctx);                                                                                             \
+    return e_dense<CT>(ctx, out0, a, false);                                                                  \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_dense(CTX, A2(TT) * *out0, const CSC(TT) * a) {                                \
+    ENTER(ctx);                                                                                             \
+    return e_dense<CT>(ctx, out0, a, true);                                                                   \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_scale(CTX, CSR(TT) * *out0, const CT v, const CSR(TT) * a) {                   \
+    ENTER(ctx);                                                                                             \
+    return e_scale<CT>(ctx, out0, v, a);                                                                      \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_scale(CTX, CSC(TT) * *out0, const CT v, const CSC(TT) * a) {                   \
+    ENTER(ctx);                                                                                             \
+    return e_scale<CT>(ctx, out0, v, a);                                                                      \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_nnz(CTX, int64_t *out0, const CSR(TT) * a) {                                   \
+    ENTER(ctx);                                                                                             \
+    return count_nonzero<CT>(ctx, a->b, out0);                                                                \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_nnz(CTX, int64_t *out0, const CSC(TT) * a) {                                   \
+    ENTER(ctx);                                                                                             \
+    return count_nonzero<CT>(ctx, a->b, out0);                                                                \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_coo(CTX, struct futhark_i64_1d **out0, struct futhark_i64_1d **out1,           \
+                                   A1(TT) * *out2, const CSR(TT) * a) {                                       \
+    ENTER(ctx);                                                                                             \
+    return e_coo<CT>(ctx, out0, out1, out2, a, false);                                                        \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_coo(CTX, struct futhark_i64_1d **out0, struct futhark_i64_1d **out1,           \
+                                   A1(TT) * *out2, const CSC(TT) * a) {                                       \
+    ENTER(ctx);                                                                                             \
+    return e_coo<CT>(ctx, out0, out1, out2, a, true);                                                         \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_add(CTX, CSR(TT) * *out0, const CSR(TT) * a, const CSR(TT) * b) {              \
+    ENTER(ctx);                                                                                             \
+    return e_addsub<CT>(ctx, out0, a, b, false);                                                              \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_sub(CTX, CSR(TT) * *out0, const CSR(TT) * a, const CSR(TT) * b) {              \
+    ENTER(ctx);                                                                                             \
+    return e_addsub<CT>(ctx, out0, a, b, true);                                                               \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_add(CTX, CSC(TT) * *out0, const CSC(TT) * a, const CSC(TT) * b) {              \
+    ENTER(ctx);                                                                                             \
+    return e_addsub<CT>(ctx, out0, a, b, false);                                                              \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_sub(CTX, CSC(TT) * *out0, const CSC(TT) * a, const CSC(TT) * b) {              \
+    ENTER(ctx);                                                                                             \
+    return e_addsub<CT>(ctx, out0, a, b, true);                                                               \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_transpose(CTX, CSC(TT) * *out0, const CSR(TT) * a) {                           \
+    ENTER(ctx);                                                                                             \
+    return e_relabel(ctx, out0, a);                                                                           \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_transpose(CTX, CSR(TT) * *out0, const CSC(TT) * a) {                           \
+    ENTER(ctx);                                                                                             \
+    return e_relabel(ctx, out0, a);                                                                           \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_smvm(CTX, A1(TT) * *out0, const CSR(TT) * a, const A1(TT) * x) {               \
+    ENTER(ctx);                                                                                             \
+    return e_smvm<CT>(ctx, out0, a, x);                                                                       \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_vsmm(CTX, A1(TT) * *out0, const A1(TT) * a, const CSC(TT) * b) {               \
+    ENTER(ctx); /* sr.smvm (transpose b) a */                                                               \
+    return e_smvm<CT>(ctx, out0, b, a);                                                                       \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_smm(CTX, A2(TT) * *out0, const CSR(TT) * a, const A2(TT) * b) {                \
+    ENTER(ctx);                                                                                             \
+    return e_smm<CT>(ctx, out0, a, b);                                                                        \
+  }                                                                                                           \
+  int futhark_entry_csr_##TT##_to_csc(CTX, CSC(TT) * *out0, const CSR(TT) * a) {                              \
+    ENTER(ctx);                                                                                             \
+    return e_convert<CT>(ctx, out0, a);                                                                       \
+  }                                                                                                           \
+  int futhark_entry_csc_##TT##_to_csr(CTX, CSR(TT) * *out0, const CSC(TT) * a) {                              \
+    ENTER(ctx);                                                                                             \
+    return e_convert<CT>(ctx, out0, a);                                                                       \
+  }                                                                                                           \
+  int futhark_entry_smsmm_##TT(CTX, CSR(TT) * *out0, const CSR(TT) * a, const CSC(TT) * b) {                  \
+    ENTER(ctx);                                                                                             \
+    return e_smsmm<CT>(ctx, out0, a, b);                                                                      \
+  }                                                                                                           \
+  int sparse_amd_csr_##TT##_dims(CTX, const CSR(TT) * a, int64_t *n, int64_t *m, int64_t *stored) {           \
+    (void)ctx;                                                                                                \
+    *n = a->b->n; *m = a->b->m; *stored = a->b->nnz;                                                          \
+    return 0;                                                                                                 \
+  }                                                                                                           \
+  int sparse_amd_csc_##TT##_dims(CTX, const CSC(TT) * a, int64_t *n, int64_t *m, int64_t *stored) {           \
+    (void)ctx;                                                                                                \
+    *n = a->b->n; *m = a->b->m; *stored = a->b->nnz;                                                          \
+    return 0;                                                                                                 \
+  }                                                                                                           \
+  int sparse_amd_csr_##TT##_fields(CTX, struct futhark_i64_1d **row_off, struct futhark_i64_1d **col_idx,     \
+                                   A1(TT) * *vals, const CSR(TT) * a) {                                       \
+    ENTER(ctx);                                                                                             \
+    return e_fields<CT>(ctx, row_off, col_idx, vals, a);                                                      \
+  }                                                                                                           \
+  int sparse_amd_csc_##TT##_fields(CTX, struct futhark_i64_1d **row_off, struct futhark_i64_1d **col_idx,     \
+                                   A1(TT) * *vals, const CSC(TT) * a) {                                       \
+    ENTER(ctx);                                                                                             \
+    return e_fields<CT>(ctx, row_off, col_idx, vals, a);                                                      \
+  }                                                                                                           \
+  int sparse_amd_csr_##TT##_from_fields(CTX, CSR(TT) * *out0, const int64_t n, const int64_t m,               \
+                                        I64A *row_off, I64A *col_idx, const A1(TT) * vals) {                  \
+    ENTER(ctx);                                                                                             \
+    return e_from_fields<CT>(ctx, out0, n, m, row_off, col_idx, vals);                                        \
+  }
+
+SAMD_MATRIX(f64, double)
+SAMD_MATRIX(f32, float)
+SAMD_MATRIX(i32, int32_t)
+
+// ------------------------------------ the reference's own entries (module i32)
+// Each body is the composition written in compressed_test.fut at the cited lines.
+typedef struct futhark_opaque_csr_i32 csr_i32;
+typedef struct futhark_opaque_csc_i32 csc_i32;
+typedef struct futhark_i32_1d arr_i32;
+typedef struct futhark_i32_2d mat_i32;
+typedef const struct futhark_i64_1d carr_i64;
+
+// compressed_test.fut:30-31  csr.eye n m |> csr.dense
+int futhark_entry_test_csr_eye(CTX, mat_i32 **out0, const int64_t in0, const int64_t in1) {
+  ENTER(ctx);
+  csr_i32 *a = nullptr;
+  SAMD_TRY(e_eye<int32_t>(ctx, &a, in0, in1));
+  int rc = e_dense<int32_t>(ctx, out0, a, false);
+  free_handle(ctx, a);
+  return rc;
+}
+// :44-45  csr.sparse n m (zip3 xs ys vs) |> csr.dense
+int futhark_entry_test_csr_sparse(CTX, mat_i32 **out0, const int64_t in0, const int64_t in1, carr_i64 *in2,
+                                  carr_i64 *in3, const arr_i32 *in4) {
+  ENTER(ctx);
+  csr_i32 *a = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  int rc = e_dense<int32_t>(ctx, out0, a, false);
+  free_handle(ctx, a);
+  return rc;
+}
+// :57-59  csr.smvm (csr.sparse n m ...) v
+int futhark_entry_test_csr_smvm(CTX, arr_i32 **out0, const int64_t in0, const int64_t in1, carr_i64 *in2,
+                                carr_i64 *in3, const arr_i32 *in4, const arr_i32 *in5) {
+  ENTER(ctx);
+  csr_i32 *a = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  int rc = e_smvm<int32_t>(ctx, out0, a, in5);
+  free_handle(ctx, a);
+  return rc;
+}
+// :68-69
+int futhark_entry_test_csr_nnz(CTX, int64_t *out0, const int64_t in0, const int64_t in1, carr_i64 *in2,
+                               carr_i64 *in3, const arr_i32 *in4) {
+  ENTER(ctx);
+  csr_i32 *a = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  int rc = count_nonzero<int32_t>(ctx, a->b, out0);
+  free_handle(ctx, a);
+  return rc;
+}
+// :76-78
+int futhark_entry_test_csr_coo(CTX, struct futhark_i64_1d **out0, struct futhark_i64_1d **out1, arr_i32 **out2,
+                               const int64_t in0, const int64_t in1, carr_i64 *in2, carr_i64 *in3,
+                               const arr_i32 *in4) {
+  ENTER(ctx);
+  csr_i32 *a = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  int rc = e_coo<int32_t>(ctx, out0, out1, out2, a, false);
+  free_handle(ctx, a);
+  return rc;
+}
+// :104-105  csc.eye n m |> csc.dense
+int futhark_entry_test_csc_eye(CTX, mat_i32 **out0, const int64_t in0, const int64_t in1) {
+  ENTER(ctx);
+  csc_i32 *a = nullptr;
+  SAMD_TRY(e_eye<int32_t>(ctx, &a, in1, in0));
+  int rc = e_dense<int32_t>(ctx, out0, a, true);
+  free_handle(ctx, a);
+  return rc;
+}
+// :118-119
+int futhark_entry_test_csc_sparse(CTX, mat_i32 **out0, const int64_t in0, const int64_t in1, carr_i64 *in2,
+                                  carr_i64 *in3, const arr_i32 *in4) {
+  ENTER(ctx);
+  csc_i32 *a = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &a, in1, in0, in3, in2, in4));
+  int rc = e_dense<int32_t>(ctx, out0, a, true);
+  free_handle(ctx, a);
+  return rc;
+}
+// :128-129
+int futhark_entry_test_csc_nnz(CTX, int64_t *out0, const int64_t in0, const int64_t in1, carr_i64 *in2,
+                               carr_i64 *in3, const arr_i32 *in4) {
+  ENTER(ctx);
+  csc_i32 *a = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &a, in1, in0, in3, in2, in4));
+  int rc = count_nonzero<int32_t>(ctx, a->b, out0);
+  free_handle(ctx, a);
+  return rc;
+}
+// :136-138
+int futhark_entry_test_csc_coo(CTX, struct futhark_i64_1d **out0, struct futhark_i64_1d **out1, arr_i32 **out2,
+                               const int64_t in0, const int64_t in1, carr_i64 *in2, carr_i64 *in3,
+                               const arr_i32 *in4) {
+  ENTER(ctx);
+  csc_i32 *a = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &a, in1, in0, in3, in2, in4));
+  int rc = e_coo<int32_t>(ctx, out0, out1, out2, a, true);
+  free_handle(ctx, a);
+  return rc;
+}
+// :145-147  csr.sparse n m ... |> csr.transpose |> csc.dense
+int futhark_entry_test_csr_transpose(CTX, mat_i32 **out0, const int64_t in0, const int64_t in1, carr_i64 *in2,
+                                     carr_i64 *in3, const arr_i32 *in4) {
+  ENTER(ctx);
+  csr_i32 *a = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  csc_i32 *t = nullptr;
+  e_relabel(ctx, &t, a);
+  int rc = e_dense<int32_t>(ctx, out0, t, true);
+  free_handle(ctx, t);
+  free_handle(ctx, a);
+  return rc;
+}
+// :154-156  csc.sparse n m ... |> csc.transpose |> csr.dense
+int futhark_entry_test_csc_transpose(CTX, mat_i32 **out0, const int64_t in0, const int64_t in1, carr_i64 *in2,
+                                     carr_i64 *in3, const arr_i32 *in4) {
+  ENTER(ctx);
+  csc_i32 *a = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &a, in1, in0, in3, in2, in4));
+  csr_i32 *t = nullptr;
+  e_relabel(ctx, &t, a);
+  int rc = e_dense<int32_t>(ctx, out0, t, false);
+  free_handle(ctx, t);
+  free_handle(ctx, a);
+  return rc;
+}
+// :172-178
+int futhark_entry_test_smsmm(CTX, mat_i32 **out0, const int64_t in0, const int64_t in1, const int64_t in2,
+                             carr_i64 *in3, carr_i64 *in4, const arr_i32 *in5, carr_i64 *in6, carr_i64 *in7,
+                             const arr_i32 *in8) {
+  ENTER(ctx);
+  csr_i32 *A = nullptr;
+  csc_i32 *B = nullptr;
+  csr_i32 *C = nullptr;
+  SAMD_TRY(e_sparse<int32_t>(ctx, &A, in0, in1, in3, in4, in5));
+  int rc = e_sparse<int32_t>(ctx, &B, in2, in1, in7, in6, in8);  // csc.sparse m k = sr.sparse k m (swap)
+  if (rc == 0) rc = e_smsmm<int32_t>(ctx, &C, A, B);
+  if (rc == 0) rc = e_dense<int32_t>(ctx, out0, C, false);
+  free_handle(ctx, C);
+  free_handle(ctx, B);
+  free_handle(ctx, A);
+  return rc;
+}
+
+}  // extern "C"

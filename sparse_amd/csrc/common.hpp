@@ -1,0 +1,253 @@
+// common.hpp -- context, device-memory pool, array/opaque records, error plumbing.
+//
+// One context = one HIP device + one stream.  All library work is stream-ordered
+// on that stream, so a block released to the pool can be handed to a later
+// operation without further synchronisation.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include "../../include/sparse_amd.h"
+
+namespace samd {
+
+// ------------------------------------------------------------------ pool
+// Size-bucketed free list in front of hipMalloc/hipFree (the generated Futhark
+// runtimes keep the same kind of free list): steady-state entry calls allocate
+// nothing from the driver.
+class Pool {
+ public:
+  void *alloc(size_t bytes, hipError_t *err) {
+    size_t need = round_up(bytes);
+    auto it = free_.lower_bound(need);
+    if (it != free_.end() && it->first <= need + need / 2 + 4096) {
+      void *p = it->second;
+      size_t sz = it->first;
+      free_.erase(it);
+      live_[p] = sz;
+      cached_ -= sz;
+      return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      clear();
+      e = hipMalloc(&p, need);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      *err = e;
+      return nullptr;
+    }
+    live_[p] = need;
+    total_ += need;
+    if (total_ > peak_) peak_ = total_;
+    return p;
+  }
+  void release(void *p) {
+    if (!p) return;
+    auto it = live_.find(p);
+    if (it == live_.end()) return;  // not ours (wrapped memory)
+    free_.emplace(it->second, p);
+    cached_ += it->second;
+    live_.erase(it);
+  }
+  void clear() {
+    for (auto &kv : free_) {
+      (void)hipFree(kv.second);
+      total_ -= kv.first;
+    }
+    free_.clear();
+    cached_ = 0;
+  }
+  size_t total() const { return total_; }
+  size_t peak() const { return peak_; }
+  size_t cached() const { return cached_; }
+  size_t live_blocks() const { return live_.size(); }
+
+ private:
+  static size_t round_up(size_t b) {
+    if (b < 256) return 256;
+    return (b + 255) & ~size_t(255);
+  }
+  std::multimap<size_t, void *> free_;
+  std::unordered_map<void *, size_t> live_;
+  size_t total_ = 0, peak_ = 0, cached_ = 0;
+};
+
+}  // namespace samd
+
+// ------------------------------------------------------------- C-visible records
+struct futhark_context_config {
+  int device = 0;
+  int debugging = 0, profiling = 0, logging = 0;
+};
+
+struct futhark_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  int num_cu = 256;
+  int logging = 0;
+  std::mutex mu;
+  std::string err;
+  bool has_err = false;
+  samd::Pool pool;
+  // pinned staging for small device->host reads (counts, flags)
+  int64_t *h_small = nullptr;  // 16 int64
+  int64_t *d_small = nullptr;  // 16 int64
+  // options (sparse_amd_context_set_option)
+  int64_t opt_spmv_algo = 0;
+  int64_t opt_spmv_lanes = 0;
+  int64_t opt_wide_col = 0;
+  int64_t opt_spmv_tile = 0;
+  // statistics for futhark_context_report
+  int64_t n_entries = 0;
+};
+
+namespace samd {
+
+inline int set_error(futhark_context *ctx, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  ctx->err = buf;
+  ctx->has_err = true;
+  return 1;
+}
+
+#define SAMD_HIP(ctx, call)                                                                  \
+  do {                                                                                       \
+    hipError_t e__ = (call);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      (void)hipGetLastError();                                                               \
+      return samd::set_error(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),    \
+                             __FILE__, __LINE__);                                            \
+    }                                                                                        \
+  } while (0)
+
+#define SAMD_TRY(expr)        \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+// Every kernel launch is followed by this: catches bad launch configurations at
+// the call site instead of at the next synchronisation.
+#define SAMD_LAUNCH_CHECK(ctx) SAMD_HIP(ctx, hipGetLastError())
+
+template <class T>
+inline int dalloc(futhark_context *ctx, T **out, int64_t count) {
+  hipError_t e = hipSuccess;
+  size_t bytes = sizeof(T) * (size_t)(count > 0 ? count : 1);
+  void *p = ctx->pool.alloc(bytes, &e);
+  if (!p) return set_error(ctx, "device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+  *out = (T *)p;
+  return 0;
+}
+
+inline void dfree(futhark_context *ctx, void *p) { ctx->pool.release(p); }
+
+// RAII temporary from the pool.
+template <class T>
+struct Tmp {
+  futhark_context *ctx;
+  T *p = nullptr;
+  explicit Tmp(futhark_context *c) : ctx(c) {}
+  ~Tmp() { dfree(ctx, p); }
+  int get(int64_t count) { return dalloc(ctx, &p, count); }
+  T *release() { T *q = p; p = nullptr; return q; }
+  Tmp(const Tmp &) = delete;
+  Tmp &operator=(const Tmp &) = delete;
+};
+
+// Copy a few int64 from device to host through the pinned slot and wait.
+inline int read_small(futhark_context *ctx, const int64_t *d, int count, int64_t *out) {
+  SAMD_HIP(ctx, hipMemcpyAsync(ctx->h_small, d, sizeof(int64_t) * count, hipMemcpyDeviceToHost, ctx->stream));
+  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < count; i++) out[i] = ctx->h_small[i];
+  return 0;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+inline int bits_for(int64_t count) {  // bits needed to hold values 0..count-1
+  if (count <= 1) return 0;
+  return 64 - __builtin_clzll((unsigned long long)(count - 1));
+}
+
+// -------------------------------------------------------------- device arrays
+template <class T, int R>
+struct DevArray {
+  T *data = nullptr;
+  int64_t shape[R];
+  bool owned = true;
+  int64_t count() const {
+    int64_t c = 1;
+    for (int i = 0; i < R; i++) c *= shape[i];
+    return c;
+  }
+};
+
+// ---------------------------------------------------------------- CSR record
+// The reference record {row_off[n] inclusive, col_idx[nnz] i64, vals[nnz]}
+// (compressed.fut:93-96) is held as
+//   row_ptr[n+1]  int64, row_ptr[0] = 0  -> row_off = row_ptr + 1 (same bytes)
+//   col32[nnz]    int32 when m <= 2^31-1 (declared in the roofline arithmetic:
+//                 ib = 4), else col64[nnz] int64
+//   vals[nnz]     T
+// plus the nnz-balanced tiling used by the streaming kernels:
+//   tile_lb[ntiles+1]: first row whose start is >= t*tile (tile_lb[ntiles] = n)
+//   head[ntiles]     : partial sum of the row fragment that enters tile t from
+//                      an earlier tile (SpMV scratch, rewritten every call)
+template <class T>
+struct CsrBody {
+  int64_t n = 0, m = 0, nnz = 0;
+  int64_t *row_ptr = nullptr;
+  int32_t *col32 = nullptr;
+  int64_t *col64 = nullptr;
+  T *vals = nullptr;
+  // plan
+  int64_t tile = 0, ntiles = 0;
+  int64_t *tile_lb = nullptr;
+  T *head = nullptr;
+  int64_t max_row_len = -1;  // filled lazily by the SpMV dispatcher
+  int refs = 1;
+};
+
+template <class T>
+inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
+  if (!b) return;
+  if (--b->refs > 0) return;
+  dfree(ctx, b->row_ptr);
+  dfree(ctx, b->col32);
+  dfree(ctx, b->col64);
+  dfree(ctx, b->vals);
+  dfree(ctx, b->tile_lb);
+  dfree(ctx, b->head);
+  delete b;
+}
+
+template <class T>
+struct CsrGuard {  // releases a half-built body on an error path
+  futhark_context *ctx;
+  CsrBody<T> *b;
+  CsrGuard(futhark_context *c, CsrBody<T> *p) : ctx(c), b(p) {}
+  ~CsrGuard() { if (b) csr_release(ctx, b); }
+  CsrBody<T> *release() { CsrBody<T> *q = b; b = nullptr; return q; }
+};
+
+}  // namespace samd

@@ -1,0 +1,185 @@
+// scan.hpp -- wavefront/block/device-wide scans (add, max) for 32/64-bit values.
+//
+// Layout rule shared by every kernel that scans or ranks a tile: a block of 256
+// threads (4 wavefronts of 64) owns ITEMS*256 consecutive elements; wavefront w
+// owns the contiguous span [w*ITEMS*64, (w+1)*ITEMS*64) and reads it in ITEMS
+// rounds of 64 consecutive elements, so element order == (wave, round, lane)
+// order and every global access is a fully coalesced 64-lane row.
+#pragma once
+
+#include "common.hpp"
+
+namespace samd {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kScanItems = 16;
+constexpr int kScanTile = kBlock * kScanItems;
+
+struct OpAdd {
+  template <class V>
+  __device__ __forceinline__ V operator()(V a, V b) const { return a + b; }
+};
+struct OpMax {
+  template <class V>
+  __device__ __forceinline__ V operator()(V a, V b) const { return a > b ? a : b; }
+};
+
+template <class V>
+struct PtrIn {
+  const V *p;
+  __device__ __forceinline__ V operator()(int64_t i) const { return p[i]; }
+};
+
+template <class V>
+__device__ __forceinline__ V wshfl_up(V v, int d) { return __shfl_up(v, d, 64); }
+template <class V>
+__device__ __forceinline__ V wshfl(V v, int src) { return __shfl(v, src, 64); }
+template <class V>
+__device__ __forceinline__ V wshfl_xor(V v, int m) { return __shfl_xor(v, m, 64); }
+
+template <class V, class Op>
+__device__ __forceinline__ V wave_inclusive_scan(V x, Op op, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    V y = wshfl_up(x, d);
+    if (lane >= d) x = op(y, x);
+  }
+  return x;
+}
+
+template <class V, class Op>
+__device__ __forceinline__ V wave_reduce(V x, Op op) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x = op(x, wshfl_xor(x, d));
+  return x;
+}
+
+// Inclusive scan of the block's ITEMS*256 striped items (layout rule above).
+// sh: at least kWaves elements of shared memory.  Ends with a barrier so sh can
+// be reused by the caller.
+template <class V, class Op, int ITEMS>
+__device__ __forceinline__ void block_scan_striped(V (&v)[ITEMS], V ident, Op op, V *sh, V &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  V carry = ident;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    V x = wave_inclusive_scan(v[k], op, lane);
+    x = op(carry, x);
+    v[k] = x;
+    carry = wshfl(x, 63);
+  }
+  if (lane == 63) sh[wave] = carry;
+  __syncthreads();
+  V off = ident, tot = ident;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    V s = sh[w];
+    if (w < wave) off = op(off, s);
+    tot = op(tot, s);
+  }
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) v[k] = op(off, v[k]);
+  total = tot;
+  __syncthreads();
+}
+
+// One value per thread: exclusive add-scan over the block (+ total).
+template <class V>
+__device__ __forceinline__ V block_exclusive_add(V x, V *sh, V &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  V inc = wave_inclusive_scan(x, OpAdd(), lane);
+  if (lane == 63) sh[wave] = inc;
+  __syncthreads();
+  V off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    V s = sh[w];
+    if (w < wave) off += s;
+    tot += s;
+  }
+  total = tot;
+  __syncthreads();
+  return off + inc - x;
+}
+
+template <class V, class Op, class In>
+__global__ __launch_bounds__(kBlock) void scan_reduce_kernel(In in, int64_t n, V ident, Op op, V *sums) {
+  __shared__ V sh[kWaves];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  V acc = ident;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    int64_t i = base + k * kBlock + threadIdx.x;
+    if (i < n) acc = op(acc, in(i));
+  }
+  acc = wave_reduce(acc, op);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    V t = ident;
+    for (int w = 0; w < kWaves; w++) t = op(t, sh[w]);
+    sums[blockIdx.x] = t;
+  }
+}
+
+// out may alias the input array: every element is read into registers before
+// the block's first barrier and written only after it.
+template <class V, class Op, class In, bool EXCLUSIVE_ADD>
+__global__ __launch_bounds__(kBlock) void scan_apply_kernel(In in, int64_t n, V ident, Op op,
+                                                           const V *sums_incl, V *out, V *d_total) {
+  __shared__ V sh[kWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)wave * (kScanItems * 64) + lane;
+  V x[kScanItems], v[kScanItems];
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    int64_t i = base + k * 64;
+    x[k] = i < n ? in(i) : ident;
+    v[k] = x[k];
+  }
+  V total;
+  block_scan_striped<V, Op, kScanItems>(v, ident, op, sh, total);
+  const V off = (sums_incl != nullptr && blockIdx.x > 0) ? sums_incl[blockIdx.x - 1] : ident;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    int64_t i = base + k * 64;
+    if (i < n) {
+      V r = op(off, v[k]);
+      out[i] = EXCLUSIVE_ADD ? (V)(r - x[k]) : r;
+    }
+  }
+  if (d_total != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *d_total = op(off, total);
+}
+
+// Device-wide scan (reduce-then-scan, three launches per level).
+//   EXCLUSIVE_ADD=false: inclusive scan under op.
+//   EXCLUSIVE_ADD=true : exclusive prefix sum (op must be OpAdd).
+// d_total (optional, device) receives the reduction of all n inputs.
+template <class V, class Op, class In, bool EXCLUSIVE_ADD>
+int device_scan(futhark_context *ctx, In in, int64_t n, V ident, Op op, V *out, V *d_total) {
+  if (n <= 0) {
+    if (d_total) SAMD_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(V), ctx->stream));  // ident is 0 for every use here
+    return 0;
+  }
+  const int64_t nblocks = cdiv(n, kScanTile);
+  if (nblocks > 0x7fffffffLL) return set_error(ctx, "scan: input too large");
+  if (nblocks == 1) {
+    hipLaunchKernelGGL((scan_apply_kernel<V, Op, In, EXCLUSIVE_ADD>), dim3(1), dim3(kBlock), 0, ctx->stream, in, n,
+                       ident, op, (const V *)nullptr, out, d_total);
+    SAMD_LAUNCH_CHECK(ctx);
+    return 0;
+  }
+  Tmp<V> sums(ctx);
+  SAMD_TRY(sums.get(nblocks));
+  hipLaunchKernelGGL((scan_reduce_kernel<V, Op, In>), dim3((unsigned)nblocks), dim3(kBlock), 0, ctx->stream, in, n,
+                     ident, op, sums.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  SAMD_TRY((device_scan<V, Op, PtrIn<V>, false>(ctx, PtrIn<V>{sums.p}, nblocks, ident, op, sums.p, (V *)nullptr)));
+  hipLaunchKernelGGL((scan_apply_kernel<V, Op, In, EXCLUSIVE_ADD>), dim3((unsigned)nblocks), dim3(kBlock), 0,
+                     ctx->stream, in, n, ident, op, (const V *)sums.p, out, d_total);
+  SAMD_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
+}  // namespace samd

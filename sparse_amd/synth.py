@@ -1,0 +1,106 @@
+"""Seeded synthetic inputs (host side, numpy).
+
+Everything derives from splitmix64 on (seed, index), a counter-based generator,
+so any slice of any input can be regenerated independently (per-rank shards in
+the multi-GPU bench) and the C twin in oracle/compressed_oracle.c agrees bit for
+bit.  Shapes follow BASELINE.json's configs.
+"""
+import numpy as np
+
+_U64 = np.uint64
+
+
+def splitmix64(seed, index):
+    """Vectorised splitmix64 finaliser of seed + (index+1)*golden."""
+    with np.errstate(over="ignore"):
+        idx = np.asarray(index, dtype=np.uint64)
+        z = _U64(seed & 0xFFFFFFFFFFFFFFFF) + (idx + _U64(1)) * _U64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> _U64(27))) * _U64(0x94D049BB133111EB)
+        return z ^ (z >> _U64(31))
+
+
+def uniform01(seed, count, start=0):
+    """f64 uniform in [0,1) from the top 53 bits."""
+    z = splitmix64(seed, np.arange(start, start + count, dtype=np.uint64))
+    return (z >> _U64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def uniform_values(seed, count, dtype, start=0):
+    """Matrix/vector values: floats uniform in [0.5,1.5) (positive, so relative
+    tolerances are meaningful); i32 uniform in [-9,9] (exact arithmetic)."""
+    if dtype == "i32":
+        z = splitmix64(seed, np.arange(start, start + count, dtype=np.uint64))
+        return ((z % _U64(19)).astype(np.int64) - 9).astype(np.int32)
+    u = uniform01(seed, count, start) + 0.5
+    return u.astype(np.float64 if dtype == "f64" else np.float32)
+
+
+def random_uniform_coo(n, m, nnz0, dtype, seed=42):
+    """C1/C5 shape: uniform random (r,c) triples; duplicates occur naturally."""
+    i = np.arange(nnz0, dtype=np.uint64)
+    r = (splitmix64(seed, i) % _U64(n)).astype(np.int64)
+    c = (splitmix64(seed + 1, i) % _U64(m)).astype(np.int64)
+    return r, c, uniform_values(seed + 2, nnz0, dtype)
+
+
+def laplacian_2d_coo(g, dtype="f64", row_lo=0, row_hi=None):
+    """C2 shape: 5-point stencil on a g x g grid, rows [row_lo,row_hi) of the
+    n=g*g matrix, emitted row-major: (i,i)=4, (i,i+-1)=-1 in-row, (i,i+-g)=-1."""
+    n = g * g
+    row_hi = n if row_hi is None else row_hi
+    i = np.arange(row_lo, row_hi, dtype=np.int64)
+    gx = i % g
+    gy = i // g
+    rows = [i, i[gx > 0], i[gx < g - 1], i[gy > 0], i[gy < g - 1]]
+    cols = [i, i[gx > 0] - 1, i[gx < g - 1] + 1, i[gy > 0] - g, i[gy < g - 1] + g]
+    vals = [np.full(len(rows[0]), 4)] + [np.full(len(r), -1) for r in rows[1:]]
+    r = np.concatenate(rows)
+    c = np.concatenate(cols)
+    v = np.concatenate(vals).astype({"f64": np.float64, "f32": np.float32, "i32": np.int32}[dtype])
+    return r, c, v
+
+
+def affine_shuffle(count, seed=42):
+    """A cheap deterministic permutation i -> (a*i + b) mod count, a coprime to count."""
+    if count <= 1:
+        return np.arange(count, dtype=np.int64)
+    a = int(splitmix64(seed, 0) % _U64(count)) | 1
+    while np.gcd(a, count) != 1:
+        a += 2
+    b = int(splitmix64(seed, 1) % _U64(count))
+    i = np.arange(count, dtype=np.uint64)
+    # a*i can exceed 2^64 for count > 2^32; counts used here are < 2^32
+    return ((i * _U64(a % count) + _U64(b)) % _U64(count)).astype(np.int64)
+
+
+def banded_coo(n, half_bw, dtype, seed=42):
+    """C4 shape: banded n x n, 2*half_bw+1 entries per row clipped at the edges."""
+    i = np.arange(n, dtype=np.int64)
+    rs, cs = [], []
+    for d in range(-half_bw, half_bw + 1):
+        ok = (i + d >= 0) & (i + d < n)
+        rs.append(i[ok])
+        cs.append(i[ok] + d)
+    r = np.concatenate(rs)
+    c = np.concatenate(cs)
+    return r, c, uniform_values(seed, len(r), dtype)
+
+
+def rmat_coo(scale, edge_factor, dtype, seed=42, probs=(0.57, 0.19, 0.19, 0.05), start=0, count=None):
+    """C3 shape: RMAT edges; edge e draws one quadrant per bit level from
+    splitmix64(seed+level, e).  Duplicates are left for assembly to merge."""
+    n = 1 << scale
+    total = n * edge_factor
+    count = total - start if count is None else count
+    e = np.arange(start, start + count, dtype=np.uint64)
+    r = np.zeros(count, np.int64)
+    c = np.zeros(count, np.int64)
+    a, b, cc, _ = probs
+    for lvl in range(scale):
+        u = (splitmix64(seed + 101 * (lvl + 1), e) >> _U64(11)).astype(np.float64) * (1.0 / (1 << 53))
+        rbit = (u >= a + b).astype(np.int64)
+        cbit = (((u >= a) & (u < a + b)) | (u >= a + b + cc)).astype(np.int64)
+        r = (r << 1) | rbit
+        c = (c << 1) | cbit
+    return r, c, uniform_values(seed + 7, count, dtype, start)
