@@ -326,7 +326,8 @@ int futhark_entry_test_smsmm(struct futhark_context *ctx, struct futhark_i32_2d 
 /* ------------------------------------------------- (3) context extensions
  * No counterpart in the generated API. */
 /* Run all subsequent work on the caller's HIP stream (hipStream_t); the context
- * first drains its current stream.  NULL restores the context's own stream. */
+ * first drains its current stream.  NULL is the HIP null stream (what torch calls
+ * its default stream), not "no stream". */
 int sparse_amd_context_set_stream(struct futhark_context *ctx, void *hip_stream);
 void *sparse_amd_context_get_stream(struct futhark_context *ctx);
 /* Tuning / test overrides.  Keys: "spmv_algo" (0 auto, 1 nnz-split stream,

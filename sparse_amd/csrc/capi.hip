@@ -375,7 +375,7 @@ char *futhark_context_report(struct futhark_context *ctx) {
 int sparse_amd_context_set_stream(struct futhark_context *ctx, void *hip_stream) {
   ENTER(ctx);
   SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->stream = (hipStream_t)hip_stream;  // NULL is the HIP null stream (torch's default stream)
   return 0;
 }
 void *sparse_amd_context_get_stream(struct futhark_context *ctx) { return (void *)ctx->stream; }

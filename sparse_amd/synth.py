@@ -104,3 +104,54 @@ def rmat_coo(scale, edge_factor, dtype, seed=42, probs=(0.57, 0.19, 0.19, 0.05),
         r = (r << 1) | rbit
         c = (c << 1) | cbit
     return r, c, uniform_values(seed + 7, count, dtype, start)
+
+
+# ---------------------------------------------------------------- device side
+# Same shapes generated directly in HBM with torch (plumbing only: device
+# memory and index arithmetic), for inputs too large to ship over PCIe quickly.
+def laplacian_2d_coo_device(g, device, dtype="f64", shuffle=True, row_lo=0, row_hi=None):
+    """C2 shape on the device; entries optionally permuted by an affine map so
+    assembly sees unsorted input.  Returns (rs, cs, vs) torch tensors."""
+    import torch
+    n = g * g
+    row_hi = n if row_hi is None else row_hi
+    i = torch.arange(row_lo, row_hi, dtype=torch.int64, device=device)
+    gx = i % g
+    gy = i // g
+    tdt = {"f64": torch.float64, "f32": torch.float32, "i32": torch.int32}[dtype]
+    masks = [None, gx > 0, gx < g - 1, gy > 0, gy < g - 1]
+    offs = [0, -1, 1, -g, g]
+    rs, cs, vs = [], [], []
+    for msk, off in zip(masks, offs):
+        r = i if msk is None else i[msk]
+        rs.append(r)
+        cs.append(r + off)
+        vs.append(torch.full((r.numel(),), 4 if off == 0 else -1, dtype=tdt, device=device))
+    r = torch.cat(rs)
+    c = torch.cat(cs)
+    v = torch.cat(vs)
+    del rs, cs, vs
+    if shuffle:
+        cnt = r.numel()
+        a = int(splitmix64(42, 0) % _U64(cnt)) | 1
+        while np.gcd(a, cnt) != 1:
+            a += 2
+        a %= cnt
+        b = int(splitmix64(42, 1) % _U64(cnt))
+        # (a*k + b) mod cnt without overflowing int64: a, k < 2^31 in every use here
+        assert cnt < (1 << 31)
+        p = (torch.arange(cnt, dtype=torch.int64, device=device) * a + b) % cnt
+        r, c, v = r[p], c[p], v[p]
+    return r.contiguous(), c.contiguous(), v.contiguous()
+
+
+def laplacian_2d_apply_device(g, x):
+    """y = A x for the 5-point stencil, computed without the matrix (property check)."""
+    import torch
+    X = x.reshape(g, g)
+    Y = 4 * X
+    Y[:, 1:] -= X[:, :-1]
+    Y[:, :-1] -= X[:, 1:]
+    Y[1:, :] -= X[:-1, :]
+    Y[:-1, :] -= X[1:, :]
+    return Y.reshape(-1)

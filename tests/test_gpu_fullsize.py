@@ -1,0 +1,78 @@
+"""Full-size (BASELINE.json configs[1]: 5-point Laplacian, 4096^2 grid, 8.4e7 entries)
+checks through properties that do not need the oracle at that size."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    from sparse_amd import Context, mk_compressed, synth
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    M = mk_compressed("f64", ctx)
+    g = 4096
+    r, c, v = synth.laplacian_2d_coo_device(g, "cuda:0")
+    A = M.sr.sparse(g * g, g * g, (r, c, v))
+    del r, c, v
+    torch.cuda.empty_cache()
+    return torch, ctx, M, A, g
+
+
+def test_c2_structure(setup):
+    torch, ctx, M, A, g = setup
+    n = g * g
+    assert A.stored_dims() == (n, n, 5 * n - 4 * g)
+    ro, ci, va = A.fields()
+    ro_t = torch.as_tensor(ro, device="cuda:0")
+    ci_t = torch.as_tensor(ci, device="cuda:0")
+    # row_off: inclusive prefix sum of the stencil's row lengths
+    i = torch.arange(n, device="cuda:0")
+    gx, gy = i % g, i // g
+    lens = 1 + (gx > 0).long() + (gx < g - 1).long() + (gy > 0).long() + (gy < g - 1).long()
+    assert torch.equal(ro_t, torch.cumsum(lens, 0))
+    # columns strictly increasing inside every row
+    starts = torch.zeros(5 * n - 4 * g, dtype=torch.bool, device="cuda:0")
+    starts[0] = True
+    starts[ro_t[:-1]] = True
+    inc = ci_t[1:] > ci_t[:-1]
+    assert bool(torch.all(inc | starts[1:]))
+    # the matrix is symmetric: its CSC record equals its CSR record, bit for bit
+    T = M.sr.to_sc(A)
+    ro2, ci2, va2 = T.fields()
+    assert torch.equal(torch.as_tensor(ro2, device="cuda:0"), ro_t)
+    assert torch.equal(torch.as_tensor(ci2, device="cuda:0"), ci_t)
+    assert torch.equal(torch.as_tensor(va2, device="cuda:0"), torch.as_tensor(va, device="cuda:0"))
+
+
+def test_c2_smvm_equals_stencil(setup):
+    torch, ctx, M, A, g = setup
+    from sparse_amd import synth
+    n = g * g
+    x = 1.0 + (torch.arange(n, device="cuda:0") % 7).double() / 8.0   # exactly representable: sums are exact
+    y = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0")
+    assert torch.equal(y, synth.laplacian_2d_apply_device(g, x))
+    # linearity on exactly representable data: A(2x + e_k) = 2 A x + A e_k
+    e = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    e[12345] = 1.0
+    lhs = torch.as_tensor(M.sr.smvm(A, 2 * x + e), device="cuda:0")
+    rhs = 2 * y + torch.as_tensor(M.sr.smvm(A, e), device="cuda:0")
+    assert torch.equal(lhs, rhs)
+    # every SpMV algorithm agrees at full size
+    for algo in (2, 3):
+        ctx.set_option("spmv_algo", algo)
+        try:
+            assert torch.equal(torch.as_tensor(M.sr.smvm(A, x), device="cuda:0"), y)
+        finally:
+            ctx.set_option("spmv_algo", 0)
+
+
+def test_c2_coo_roundtrip_is_idempotent(setup):
+    torch, ctx, M, A, g = setup
+    n = g * g
+    r, c, v = M.sr.coo(A)
+    A2 = M.sr.sparse(n, n, (r, c, v))
+    for a, b in zip(A.fields(), A2.fields()):
+        assert torch.equal(torch.as_tensor(a, device="cuda:0"), torch.as_tensor(b, device="cuda:0"))

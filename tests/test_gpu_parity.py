@@ -1,0 +1,344 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle
+on the same seeded inputs, plus the reference's own known-answer vectors.
+
+Bars (BASELINE.json north_star): index arrays bit-exact; i32 exact; f64 values
+within 1e-12 relative, f32 within 1e-5 relative.  Assembly values are in fact
+asserted bit-exact: the stable radix sort keeps duplicates in input order and
+runs are folded left to right, exactly what the oracle does.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import NP, OracleCompressed, assert_kat_equal, load_kat, random_coo, run_kat
+from oracle.oracle import Oracle
+from sparse_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+KAT = load_kat()
+RTOL = {"f64": 1e-12, "f32": 1e-5, "i32": 0}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from sparse_amd import Context
+    c = Context(0)
+    yield c
+    c.sync()
+
+
+def mk(ctx, t):
+    from sparse_amd import mk_compressed
+    return mk_compressed(t, ctx)
+
+
+def fields(A):
+    ro, ci, va = A.fields()
+    return ro.numpy(), ci.numpy(), va.numpy()
+
+
+def assert_same_record(A, want, exact_vals=True, dtype="f64"):
+    ro, ci, va = fields(A)
+    n, m, nnz = A.stored_dims()
+    assert (n, m, nnz) == (want["n"], want["m"], want["nnz"])
+    assert np.array_equal(ro, want["row_off"]), "row_off differs"
+    assert np.array_equal(ci, want["col_idx"]), "col_idx differs"
+    if exact_vals:
+        assert np.array_equal(va, want["vals"]), "vals differ"
+    else:
+        np.testing.assert_allclose(va, want["vals"], rtol=RTOL[dtype], atol=0)
+
+
+def close(got, want, dtype):
+    got = np.asarray(got)
+    if dtype == "i32":
+        assert np.array_equal(got, want)
+    else:
+        np.testing.assert_allclose(got, want, rtol=RTOL[dtype], atol=0)
+
+
+# ----------------------------------------------------------- reference KATs
+@pytest.mark.parametrize("entry,ref,inputs,want", KAT, ids=[k[0] + "@" + k[1].split(":")[1] for k in KAT])
+def test_kat_through_module_mirror(ctx, entry, ref, inputs, want):
+    assert_kat_equal(run_kat(mk(ctx, "i32"), entry, inputs), want, ref)
+
+
+_RAW_OUT = {
+    "test_csr_eye": ["i32_2d"], "test_csc_eye": ["i32_2d"], "test_csr_sparse": ["i32_2d"],
+    "test_csc_sparse": ["i32_2d"], "test_csr_transpose": ["i32_2d"], "test_csc_transpose": ["i32_2d"],
+    "test_smsmm": ["i32_2d"], "test_csr_smvm": ["i32_1d"], "test_csr_nnz": ["i64"], "test_csc_nnz": ["i64"],
+    "test_csr_coo": ["i64_1d", "i64_1d", "i32_1d"], "test_csc_coo": ["i64_1d", "i64_1d", "i32_1d"],
+}
+
+
+@pytest.mark.parametrize("entry,ref,inputs,want", KAT, ids=[k[0] + "@" + k[1].split(":")[1] for k in KAT])
+def test_kat_through_generated_entry_names(ctx, entry, ref, inputs, want):
+    """Calls futhark_entry_<name> exactly as a harness for the reference's generated library would."""
+    from sparse_amd.compressed import DeviceArray
+    L = ctx.L
+    args, keep = [], []
+    for x in inputs:
+        if isinstance(x, int):
+            args.append(ctypes.c_int64(x))
+        else:
+            d = ctx.array(x, "i64" if x.dtype == np.int64 else "i32")
+            keep.append(d)
+            args.append(d.h)
+    outs = []
+    for kind in _RAW_OUT[entry]:
+        outs.append(ctypes.c_int64() if kind == "i64" else ctypes.c_void_p())
+    rc = getattr(L, "futhark_entry_" + entry)(ctx.h, *[ctypes.byref(o) for o in outs], *args)
+    ctx.check(rc)
+    got = []
+    for kind, o in zip(_RAW_OUT[entry], outs):
+        if kind == "i64":
+            got.append(o.value)
+        else:
+            t, r = kind.split("_")
+            got.append(DeviceArray(ctx, o.value, t, int(r[0])).numpy())
+    assert_kat_equal(got, want, ref)
+
+
+# ------------------------------------------------------------ assembly parity
+SHAPES = [(1, 1, 5), (7, 5, 40), (300, 200, 5000), (1000, 1000, 20000), (64, 4096, 30000), (5000, 3, 9000),
+          (100000, 100000, 300000)]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%dx%d_%d" % s)
+def test_sparse_matches_oracle(ctx, dtype, shape):
+    n, m, k = shape
+    r, c, v = random_coo(n, m, k, dtype, seed=n + k, dup_frac=0.2)
+    O = Oracle(dtype)
+    M = mk(ctx, dtype)
+    assert_same_record(M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v))
+    assert_same_record(M.sc.sparse(n, m, (r, c, v)), O.sc_sparse(n, m, r, c, v))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "i32"])
+def test_sparse_edge_cases(ctx, dtype):
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    e = np.zeros(0, np.int64)
+    ev = np.zeros(0, NP[dtype])
+    for n, m in ((2, 3), (0, 0), (0, 4), (4, 0), (1, 1)):
+        assert_same_record(M.sr.sparse(n, m, (e, e, ev)), O.sr_sparse(n, m, e, e, ev))
+    # every triple the same coordinate: one long run, folded left to right
+    k = 5000
+    r, c = np.full(k, 3, np.int64), np.full(k, 1, np.int64)
+    v = synth.uniform_values(1, k, dtype)
+    assert_same_record(M.sr.sparse(5, 2, (r, c, v)), O.sr_sparse(5, 2, r, c, v))
+    # all rows empty but the last; single column
+    r, c = np.full(100, 999, np.int64), np.zeros(100, np.int64)
+    assert_same_record(M.sr.sparse(1000, 1, (r, c, v[:100])), O.sr_sparse(1000, 1, r, c, v[:100]))
+    # already sorted / reverse sorted input
+    r, c, v = random_coo(50, 60, 700, dtype, seed=9, dup_frac=0.0)
+    o = np.lexsort((c, r))
+    for order in (o, o[::-1]):
+        assert_same_record(M.sr.sparse(50, 60, (r[order], c[order], v[order])),
+                           O.sr_sparse(50, 60, r[order], c[order], v[order]))
+    # wide key: more than 32 key bits, and a column range past int32 (col_idx stays i64 on device)
+    n, m = 1 << 20, 1 << 33
+    r = (synth.splitmix64(5, np.arange(3000, dtype=np.uint64)) % np.uint64(n)).astype(np.int64)
+    c = (synth.splitmix64(6, np.arange(3000, dtype=np.uint64)) % np.uint64(m)).astype(np.int64)
+    v = synth.uniform_values(7, 3000, dtype)
+    assert_same_record(M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v))
+
+
+def test_sparse_rejects_out_of_range(ctx):
+    from sparse_amd.compressed import SparseError
+    M = mk(ctx, "f64")
+    for r, c in (([2], [0]), ([-1], [0]), ([0], [3]), ([0], [-1])):
+        with pytest.raises(SparseError):
+            M.sr.sparse(2, 3, (np.array(r, np.int64), np.array(c, np.int64), np.array([1.0])))
+    with pytest.raises(SparseError):
+        M.sr.sparse(2, 3, (np.array([0, 1], np.int64), np.array([0], np.int64), np.array([1.0])))
+    # the context stays usable after an error
+    A = M.sr.sparse(2, 3, (np.array([0], np.int64), np.array([1], np.int64), np.array([2.0])))
+    assert M.sr.nnz(A) == 1
+
+
+# ---------------------------------------------------------------- SpMV parity
+def skewed_coo(n, m, dtype, seed):
+    """A few very long rows, many short ones, empty stretches (power-law-like)."""
+    rs, cs = [], []
+    rs.append(np.full(m, 5, np.int64)); cs.append(np.arange(m, dtype=np.int64))             # dense row
+    rs.append(np.full(m // 2, n - 2, np.int64)); cs.append(np.arange(0, m - 1, 2, dtype=np.int64)[:m // 2])
+    k = 4 * n
+    i = np.arange(k, dtype=np.uint64)
+    u = synth.uniform01(seed, k)
+    rs.append((n // 3 + (u ** 4) * (n // 2)).astype(np.int64)); cs.append((synth.splitmix64(seed + 1, i) % np.uint64(m)).astype(np.int64))
+    r, c = np.concatenate(rs), np.concatenate(cs)
+    return r, c, synth.uniform_values(seed + 2, len(r), dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+@pytest.mark.parametrize("algo", [1, 2, 3])
+def test_smvm_matches_oracle(ctx, dtype, algo):
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    ctx.set_option("spmv_algo", algo)
+    try:
+        cases = [random_coo(1000, 1200, 9000, dtype, seed=1), random_coo(20000, 20000, 200000, dtype, seed=2),
+                 skewed_coo(3000, 9000, dtype, 3), random_coo(1, 5000, 4000, dtype, seed=4),
+                 random_coo(5000, 1, 300, dtype, seed=5)]
+        dims = [(1000, 1200), (20000, 20000), (3000, 9000), (1, 5000), (5000, 1)]
+        for (n, m), (r, c, v) in zip(dims, cases):
+            A = M.sr.sparse(n, m, (r, c, v))
+            Ao = O.sr_sparse(n, m, r, c, v)
+            x = synth.uniform_values(17, m, dtype)
+            close(M.sr.smvm(A, x), O.sr_smvm(Ao, x), dtype)
+            # vsmm on the relabelled record: a B = (B^T) a
+            a = synth.uniform_values(18, n, dtype)
+            Bt = M.sc.sparse(n, m, (r, c, v))
+            close(M.sc.vsmm(a, Bt), O.sc_vsmm(a, O.sc_sparse(n, m, r, c, v)), dtype)
+    finally:
+        ctx.set_option("spmv_algo", 0)
+
+
+def test_smvm_laplacian_and_tile_boundaries(ctx):
+    """Rows that straddle the 2048-entry tiles, rows longer than several tiles, empty rows between."""
+    O, M = Oracle("f64"), mk(ctx, "f64")
+    g = 96
+    r, c, v = synth.laplacian_2d_coo(g)
+    p = synth.affine_shuffle(len(r))
+    A = M.sr.sparse(g * g, g * g, (r[p], c[p], v[p]))
+    x = 1.0 + (np.arange(g * g) % 7) / 8.0
+    assert np.array_equal(M.sr.smvm(A, x).numpy(), O.sr_smvm(O.sr_sparse(g * g, g * g, r, c, v), x))
+    # rows of length 2047, 2049, 1, 0, 6000, 0, 0, 4096, 3
+    lens = [2047, 2049, 1, 0, 6000, 0, 0, 4096, 3]
+    m = 7000
+    rs = np.concatenate([np.full(L, i, np.int64) for i, L in enumerate(lens)])
+    cs = np.concatenate([np.arange(L, dtype=np.int64) for L in lens])
+    vs = synth.uniform_values(3, len(rs), "f64")
+    A = M.sr.sparse(len(lens), m, (rs, cs, vs))
+    x = synth.uniform_values(4, m, "f64")
+    close(M.sr.smvm(A, x), O.sr_smvm(O.sr_sparse(len(lens), m, rs, cs, vs), x), "f64")
+    # integer twin of the same structure must be exact
+    Oi, Mi = Oracle("i32"), mk(ctx, "i32")
+    vi = synth.uniform_values(3, len(rs), "i32")
+    xi = synth.uniform_values(4, m, "i32")
+    assert np.array_equal(Mi.sr.smvm(Mi.sr.sparse(len(lens), m, (rs, cs, vi)), xi).numpy(),
+                          Oi.sr_smvm(Oi.sr_sparse(len(lens), m, rs, cs, vi), xi))
+
+
+def test_smvm_empty_and_shape_errors(ctx):
+    from sparse_amd.compressed import SparseError
+    M = mk(ctx, "f64")
+    Z = M.sr.zero(4, 3)
+    assert np.array_equal(M.sr.smvm(Z, np.ones(3)).numpy(), np.zeros(4))
+    assert M.sr.smvm(M.sr.zero(0, 3), np.ones(3)).numpy().shape == (0,)
+    with pytest.raises(SparseError):
+        M.sr.smvm(Z, np.ones(4))
+
+
+def test_smvm_is_reproducible(ctx):
+    M = mk(ctx, "f64")
+    r, c, v = skewed_coo(3000, 9000, "f64", 8)
+    A = M.sr.sparse(3000, 9000, (r, c, v))
+    x = synth.uniform_values(1, 9000, "f64")
+    y0 = M.sr.smvm(A, x).numpy()
+    for _ in range(3):
+        assert np.array_equal(M.sr.smvm(A, x).numpy(), y0)
+
+
+# ------------------------------------------------- the rest of the surface
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+def test_coo_dense_nnz_scale_addsub_conversion(ctx, dtype):
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    n, m, k = 700, 500, 9000
+    r, c, v = random_coo(n, m, k, dtype, seed=21, dup_frac=0.1)
+    A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
+    for got, want in zip(M.sr.coo(A), O.sr_coo(Ao)):
+        assert np.array_equal(np.asarray(got), want)
+    B, Bo = M.sc.sparse(n, m, (r, c, v)), O.sc_sparse(n, m, r, c, v)
+    for got, want in zip(M.sc.coo(B), O.sc_coo(Bo)):
+        assert np.array_equal(np.asarray(got), want)
+    assert np.array_equal(M.sr.dense(A).numpy(), O.sr_dense(Ao))
+    assert np.array_equal(M.sc.dense(B).numpy(), O.sc_dense(Bo))
+    assert M.sr.nnz(A) == O.sr_nnz(Ao)
+    s = {"f64": 2.5, "f32": 2.5, "i32": -3}[dtype]
+    assert_same_record(M.sr.scale(s, A), O.sr_scale(s, Ao))
+    r2, c2, v2 = random_coo(n, m, k // 3, dtype, seed=22)
+    A2, A2o = M.sr.sparse(n, m, (r2, c2, v2)), O.sr_sparse(n, m, r2, c2, v2)
+    assert_same_record(M.sr.add(A, A2), O.sr_add(Ao, A2o))
+    assert_same_record(M.sr.sub(A, A2), O.sr_sub(Ao, A2o))
+    d = M.sr.sub(A, A)                       # explicit zeros are kept, nnz counts none
+    assert d.stored_dims()[2] == Ao["nnz"] and M.sr.nnz(d) == 0
+    # physical conversion and back
+    T = M.sr.to_sc(A)
+    assert_same_record(T, O.sr_to_sc(Ao))
+    assert_same_record(M.sc.to_sr(T), Ao)
+    # zero-cost transpose: same record, other label
+    assert_same_record(M.sr.transpose(A), Ao)
+    assert np.array_equal(M.sc.dense(M.sr.transpose(A)).numpy(), O.sr_dense(Ao).T)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "i32"])
+def test_constructors(ctx, dtype):
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    for n, m in ((3, 2), (2, 3), (5, 5), (0, 0), (0, 1), (1, 0), (300, 7)):
+        assert_same_record(M.sr.eye(n, m), O.sr_eye(n, m))
+        assert_same_record(M.sc.eye(n, m), O.sc_eye(n, m))
+        assert_same_record(M.sr.zero(n, m), O.sr_zero(n, m))
+    v = synth.uniform_values(2, 1000, dtype)
+    assert_same_record(M.sr.diag(v), O.sr_diag(v))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+@pytest.mark.parametrize("k", [1, 8, 64, 100])
+def test_smm_matches_oracle(ctx, dtype, k):
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    n, m = 900, 700
+    r, c, v = skewed_coo(n, m, dtype, 31)
+    A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
+    B = synth.uniform_values(32, m * k, dtype).reshape(m, k)
+    close(M.sr.smm(A, B), O.sr_smm(Ao, B), dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "i32"])
+def test_smsmm_matches_oracle(ctx, dtype):
+    Oc, M = OracleCompressed(dtype), mk(ctx, dtype)
+    n, m, k = 40, 30, 25
+    r, c, v = random_coo(n, m, 300, dtype, seed=41)
+    r2, c2, v2 = random_coo(m, k, 200, dtype, seed=42)
+    A, B = M.sr.sparse(n, m, (r, c, v)), M.sc.sparse(m, k, (r2, c2, v2))
+    Ao, Bo = Oc.sr.sparse(n, m, (r, c, v)), Oc.sc.sparse(m, k, (r2, c2, v2))
+    want = Oc.smsmm(Ao, Bo)
+    assert_same_record(M.smsmm(A, B), want, exact_vals=(dtype == "i32"), dtype=dtype)
+
+
+def test_from_fields_roundtrip(ctx):
+    from sparse_amd.compressed import SparseError
+    O, M = Oracle("f64"), mk(ctx, "f64")
+    r, c, v = random_coo(300, 400, 5000, "f64", seed=51)
+    Ao = O.sr_sparse(300, 400, r, c, v)
+    A = M.sr.from_fields(300, 400, Ao["row_off"], Ao["col_idx"], Ao["vals"])
+    assert_same_record(A, Ao)
+    x = synth.uniform_values(1, 400, "f64")
+    close(M.sr.smvm(A, x), O.sr_smvm(Ao, x), "f64")
+    bad = Ao["col_idx"].copy()
+    bad[3] = 400
+    with pytest.raises(SparseError):
+        M.sr.from_fields(300, 400, Ao["row_off"], bad, Ao["vals"])
+    bad_ro = Ao["row_off"].copy()
+    bad_ro[10] = bad_ro[9] - 1 if bad_ro[9] > 0 else 10**9
+    with pytest.raises(SparseError):
+        M.sr.from_fields(300, 400, bad_ro, Ao["col_idx"], Ao["vals"])
+
+
+def test_wide_col_option_keeps_parity(ctx):
+    """col_idx kept as i64 on device (the layout used when m > 2^31-1) gives the same results."""
+    O, M = Oracle("f64"), mk(ctx, "f64")
+    ctx.set_option("wide_col", 1)
+    try:
+        r, c, v = random_coo(2000, 3000, 30000, "f64", seed=61)
+        A, Ao = M.sr.sparse(2000, 3000, (r, c, v)), O.sr_sparse(2000, 3000, r, c, v)
+        assert_same_record(A, Ao)
+        x = synth.uniform_values(1, 3000, "f64")
+        close(M.sr.smvm(A, x), O.sr_smvm(Ao, x), "f64")
+        assert_same_record(M.sr.to_sc(A), O.sr_to_sc(Ao))
+        B = synth.uniform_values(2, 3000 * 4, "f64").reshape(3000, 4)
+        close(M.sr.smm(A, B), O.sr_smm(Ao, B), "f64")
+    finally:
+        ctx.set_option("wide_col", 0)
