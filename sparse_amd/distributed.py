@@ -1,0 +1,209 @@
+"""Row-sharded SpMV across the GPUs of one node: one process per GPU,
+torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+
+The reference has no distributed layer (Futhark targets one device); this is the
+multi-GPU step BASELINE.json's north_star asks for.  Rows are independent given x,
+so the only data-path exchange is x itself:
+
+  * rank k owns a contiguous block of rows and the matching slice of x;
+  * at set-up every rank finds which x entries its rows actually reference
+    (unique column ids), and the ranks tell each other once which of their
+    entries are wanted where (ExchangePlan);
+  * per product: each rank packs the entries its peers want, all pairs swap
+    them with grouped point-to-point sends (xGMI is a full mesh of
+    point-to-point links, so every pair uses its own link concurrently),
+    then the ordinary single-GPU kernel runs on the local rows against
+    [owned slice | received entries].
+  * when the rows reference most of x anyway (random matrices) the plan
+    degenerates to "every rank sends its whole slice to everyone", i.e. an
+    all-gather, done with one RCCL all_gather_into_tensor when slices are equal.
+
+Local column ids are remapped once (owned: c - lo; remote: n_owned + position in
+the sorted ghost list), so the per-step path has no index translation.
+"""
+import numpy as np
+
+
+def partition_rows_equal_nnz(row_off, parts):
+    """Row-block boundaries with (nearly) equal stored entries per part.
+    row_off: the reference-convention inclusive prefix sum (length n), host array.
+    Returns parts+1 ascending row indices; splitter g = upper_bound(row_off, g*nnz/parts)."""
+    row_off = np.asarray(row_off, dtype=np.int64)
+    n = len(row_off)
+    nnz = int(row_off[-1]) if n else 0
+    b = [0]
+    for g in range(1, parts):
+        b.append(int(np.searchsorted(row_off, (g * nnz) // parts, side="right")))
+    b.append(n)
+    for i in range(1, len(b)):
+        b[i] = max(b[i], b[i - 1])
+    return b
+
+
+class ExchangePlan:
+    """Who sends which x entries to whom.  Pure torch + torch.distributed; works on
+    CPU tensors with gloo (tests) and CUDA tensors with nccl/RCCL (product)."""
+
+    ALLGATHER_FRACTION = 0.5
+
+    def __init__(self, dist, bounds, needed_cols, device, force_mode=None):
+        """bounds: world+1 ascending global indices; rank k owns x[bounds[k]:bounds[k+1]].
+        needed_cols: sorted unique global column ids referenced by this rank's rows."""
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.bounds = [int(b) for b in bounds]
+        self.device = device
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self.n_own = self.hi - self.lo
+        m = self.bounds[-1]
+        remote = needed_cols[(needed_cols < self.lo) | (needed_cols >= self.hi)]
+        n_remote_total = m - self.n_own
+        # one collective decision so that every rank takes the same path
+        frac = torch.tensor([float(remote.numel()) / max(n_remote_total, 1)], dtype=torch.float64, device=device)
+        if dist is not None and self.world > 1:
+            dist.all_reduce(frac, op=dist.ReduceOp.MAX)
+        mode = "allgather" if float(frac.item()) >= self.ALLGATHER_FRACTION else "halo"
+        if force_mode:
+            mode = force_mode
+        if self.world == 1:
+            mode = "none"
+        self.mode = mode
+        bt = torch.tensor(self.bounds, dtype=torch.int64, device=device)
+        if mode in ("allgather", "none"):
+            # x_ext is the whole vector in global numbering
+            self.x_len = m
+            self.own_offset = self.lo
+            self.ghost = None
+            self.equal_slices = len({self.bounds[k + 1] - self.bounds[k] for k in range(self.world)}) == 1
+            self.send_idx = None
+            self.send_counts = [0 if k == self.rank else self.n_own for k in range(self.world)]
+            self.recv_counts = [0 if k == self.rank else self.bounds[k + 1] - self.bounds[k] for k in range(self.world)]
+            return
+        # ---- halo mode
+        self.ghost = remote.contiguous()
+        self.x_len = self.n_own + int(self.ghost.numel())
+        self.own_offset = 0
+        owner = torch.searchsorted(bt, self.ghost, right=True) - 1          # owning rank of each ghost
+        recv_counts = torch.bincount(owner, minlength=self.world).to(torch.int64)
+        self.recv_counts = [int(v) for v in recv_counts.tolist()]
+        # tell every peer how many (then which) of its entries are wanted here
+        all_counts = [torch.zeros(self.world, dtype=torch.int64, device=device) for _ in range(self.world)]
+        dist.all_gather(all_counts, recv_counts)
+        self.send_counts = [int(all_counts[p][self.rank].item()) for p in range(self.world)]
+        want_from = torch.split(self.ghost, self.recv_counts)               # ghost is sorted => grouped by owner
+        send_lists = [torch.empty(self.send_counts[p], dtype=torch.int64, device=device) for p in range(self.world)]
+        ops = []
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            if self.recv_counts[p]:
+                ops.append(dist.P2POp(dist.isend, want_from[p].contiguous(), p))
+            if self.send_counts[p]:
+                ops.append(dist.P2POp(dist.irecv, send_lists[p], p))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        self.send_idx = (torch.cat(send_lists) - self.lo) if sum(self.send_counts) else \
+            torch.empty(0, dtype=torch.int64, device=device)
+        assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_own)
+        self._sendbuf = None
+
+    # -- column numbering of the local matrix
+    def remap_cols(self, cols):
+        torch = self.torch
+        if self.mode != "halo":
+            return cols
+        own = (cols >= self.lo) & (cols < self.hi)
+        gpos = torch.searchsorted(self.ghost, cols)
+        return torch.where(own, cols - self.lo, gpos + self.n_own)
+
+    def new_x(self, dtype):
+        """The extended vector [.. owned slice ..] this rank multiplies against, and
+        the view of it that holds the owned slice."""
+        x_ext = self.torch.zeros(self.x_len, dtype=dtype, device=self.device)
+        return x_ext, x_ext[self.own_offset:self.own_offset + self.n_own]
+
+    def exchange(self, x_ext):
+        """Fill the non-owned part of x_ext from the peers (in place)."""
+        torch, dist = self.torch, self.dist
+        if self.mode == "none":
+            return x_ext
+        own = x_ext[self.own_offset:self.own_offset + self.n_own]
+        if self.mode == "allgather":
+            if self.equal_slices:
+                dist.all_gather_into_tensor(x_ext, own.clone())
+                return x_ext
+            ops = []
+            for p in range(self.world):
+                if p == self.rank:
+                    continue
+                ops.append(dist.P2POp(dist.isend, own, p))
+                ops.append(dist.P2POp(dist.irecv, x_ext[self.bounds[p]:self.bounds[p + 1]], p))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            return x_ext
+        sendbuf = own[self.send_idx]
+        recv = x_ext[self.n_own:]
+        ops, so, ro = [], 0, 0
+        for p in range(self.world):
+            sc, rc = self.send_counts[p], self.recv_counts[p]
+            if p != self.rank:
+                if sc:
+                    ops.append(dist.P2POp(dist.isend, sendbuf[so:so + sc], p))
+                if rc:
+                    ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], p))
+            so += sc
+            ro += rc
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return x_ext
+
+
+class DistCsr:
+    """This rank's row block as an ordinary single-GPU CSR record plus the plan
+    that keeps its x up to date."""
+
+    def __init__(self, M, plan, A, n_loc, torch_dtype):
+        self.M, self.plan, self.A, self.n_loc = M, plan, A, n_loc
+        self.mode = plan.mode
+        self.x_len = plan.x_len
+        self.x_ext, self.x_own = plan.new_x(torch_dtype)
+
+    @classmethod
+    def from_local_coo(cls, M, dist, n_glob, m_glob, row_lo, row_hi, rs, cs, vs, force_mode=None):
+        """rs/cs/vs: this rank's COO triples (torch CUDA tensors, GLOBAL indices, rows in
+        [row_lo,row_hi)).  x is partitioned like the rows (square matrices)."""
+        import torch
+        assert n_glob == m_glob, "x is partitioned like the rows: square matrices only"
+        dev = rs.device
+        world = dist.get_world_size() if dist is not None else 1
+        mine = torch.tensor([row_hi], dtype=torch.int64, device=dev)
+        his = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(his, mine)
+        else:
+            his = [mine]
+        bounds = [0] + [int(h.item()) for h in his]
+        assert bounds[-1] == m_glob and bounds[(dist.get_rank() if dist is not None else 0)] == row_lo
+        needed = torch.unique(cs)
+        plan = ExchangePlan(dist, bounds, needed, dev, force_mode)
+        del needed
+        A = M.sr.sparse(row_hi - row_lo, plan.x_len, (rs - row_lo, plan.remap_cols(cs), vs))
+        return cls(M, plan, A, row_hi - row_lo, vs.dtype)
+
+    def exchange(self, x_own=None):
+        if x_own is not None and x_own.data_ptr() != self.x_own.data_ptr():
+            self.x_own.copy_(x_own)
+        return self.plan.exchange(self.x_ext)
+
+    def local_smvm(self, x_ext):
+        return self.M.sr.smvm(self.A, x_ext)
+
+    def smvm(self, x_own=None):
+        """y[rows of this rank] = A[rows,:] x.  x_own: this rank's slice of x (ideally the
+        view DistCsr.x_own itself, then nothing is copied)."""
+        return self.local_smvm(self.exchange(x_own))

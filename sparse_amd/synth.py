@@ -109,17 +109,31 @@ def rmat_coo(scale, edge_factor, dtype, seed=42, probs=(0.57, 0.19, 0.19, 0.05),
 # ---------------------------------------------------------------- device side
 # Same shapes generated directly in HBM with torch (plumbing only: device
 # memory and index arithmetic), for inputs too large to ship over PCIe quickly.
-def laplacian_2d_coo_device(g, device, dtype="f64", shuffle=True, row_lo=0, row_hi=None):
-    """C2 shape on the device; entries optionally permuted by an affine map so
-    assembly sees unsorted input.  Returns (rs, cs, vs) torch tensors."""
+def _affine_perm_device(cnt, device):
     import torch
-    n = g * g
+    a = int(splitmix64(42, 0) % _U64(cnt)) | 1
+    while np.gcd(a, cnt) != 1:
+        a += 2
+    a %= cnt
+    b = int(splitmix64(42, 1) % _U64(cnt))
+    assert cnt < (1 << 31)  # a*k stays inside int64
+    return (torch.arange(cnt, dtype=torch.int64, device=device) * a + b) % cnt
+
+
+def laplacian_2d_coo_device(g, device, dtype="f64", shuffle=True, row_lo=0, row_hi=None, gy=None):
+    """5-point stencil on a gy x g grid (gy = g by default: the C2 shape), rows
+    [row_lo,row_hi) of the n = gy*g matrix, generated on the device; entries
+    optionally permuted by an affine map so assembly sees unsorted input.
+    Returns (rs, cs, vs) torch tensors with GLOBAL indices."""
+    import torch
+    gy = g if gy is None else gy
+    n = gy * g
     row_hi = n if row_hi is None else row_hi
     i = torch.arange(row_lo, row_hi, dtype=torch.int64, device=device)
-    gx = i % g
-    gy = i // g
+    x = i % g
+    y = i // g
     tdt = {"f64": torch.float64, "f32": torch.float32, "i32": torch.int32}[dtype]
-    masks = [None, gx > 0, gx < g - 1, gy > 0, gy < g - 1]
+    masks = [None, x > 0, x < g - 1, y > 0, y < gy - 1]
     offs = [0, -1, 1, -g, g]
     rs, cs, vs = [], [], []
     for msk, off in zip(masks, offs):
@@ -132,22 +146,36 @@ def laplacian_2d_coo_device(g, device, dtype="f64", shuffle=True, row_lo=0, row_
     v = torch.cat(vs)
     del rs, cs, vs
     if shuffle:
-        cnt = r.numel()
-        a = int(splitmix64(42, 0) % _U64(cnt)) | 1
-        while np.gcd(a, cnt) != 1:
-            a += 2
-        a %= cnt
-        b = int(splitmix64(42, 1) % _U64(cnt))
-        # (a*k + b) mod cnt without overflowing int64: a, k < 2^31 in every use here
-        assert cnt < (1 << 31)
-        p = (torch.arange(cnt, dtype=torch.int64, device=device) * a + b) % cnt
+        p = _affine_perm_device(r.numel(), device)
         r, c, v = r[p], c[p], v[p]
     return r.contiguous(), c.contiguous(), v.contiguous()
 
 
-def laplacian_2d_apply_device(g, x):
-    """y = A x for the 5-point stencil, computed without the matrix (property check)."""
+def laplacian_x_device(lo, hi, device):
+    """x_i = 1 + (i mod 7)/8 for global indices [lo,hi): exactly representable, so
+    every stencil sum is exact in f64 whatever the summation order."""
     import torch
+    return 1.0 + (torch.arange(lo, hi, device=device) % 7).double() / 8.0
+
+
+def laplacian_2d_apply_rows(g, gy, row_lo, row_hi, device):
+    """(A x)[row_lo:row_hi] for the stencil on a gy x g grid and x = laplacian_x_device,
+    computed from the formula alone (no matrix, no communication)."""
+    import torch
+    i = torch.arange(row_lo, row_hi, dtype=torch.int64, device=device)
+    xv = lambda j: 1.0 + (j % 7).double() / 8.0
+    x = i % g
+    y = i // g
+    out = 4.0 * xv(i)
+    out -= torch.where(x > 0, xv(i - 1), torch.zeros((), dtype=torch.float64, device=device))
+    out -= torch.where(x < g - 1, xv(i + 1), torch.zeros((), dtype=torch.float64, device=device))
+    out -= torch.where(y > 0, xv(i - g), torch.zeros((), dtype=torch.float64, device=device))
+    out -= torch.where(y < gy - 1, xv(i + g), torch.zeros((), dtype=torch.float64, device=device))
+    return out
+
+
+def laplacian_2d_apply_device(g, x):
+    """y = A x for the square 5-point stencil, computed without the matrix (property check)."""
     X = x.reshape(g, g)
     Y = 4 * X
     Y[:, 1:] -= X[:, :-1]
