@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(const int64_t *__restrict_
   tile_lb[t] = lo;
 }
 
-constexpr int64_t kPlanTile = 2048;  // entries per tile; matches the SpMV kernels' TILE
+constexpr int64_t kPlanTile = 1024;  // entries per tile; matches the SpMV kernels' TILE
 
 template <class T>
 int build_plan(futhark_context *ctx, CsrBody<T> *b) {

@@ -3,25 +3,30 @@
 //
 // The reference flattens the product (expand_outer_reduce): it materialises an
 // nnz-long row-id array, an nnz-long iota and an nnz-long product array and
-// runs segmented scans over them.  Here the product array never leaves the CU:
+// runs segmented scans over them.  Here nothing but y leaves the CU:
 //
 // spmv_stream (default; nnz-balanced, "merge-path"-style partition on entries)
-//   * tile t owns entries [t*TILE, (t+1)*TILE): col_idx/vals are streamed with
-//     128-bit coalesced loads whatever the row lengths are; x is gathered
-//     through L1/L2; products land in LDS.
-//   * rows are then reduced out of LDS: one lane per row fragment when the
-//     fragment is short, a whole wavefront (64 lanes + cross-lane reduction)
-//     for fragments longer than kLongFrag.
-//   * a row that starts in tile t is written by tile t (plain store).  The part
-//     of a row that spills into later tiles is written to head[t'] by those
+//   * tile t owns entries [t*TILE, (t+1)*TILE).  col_idx/vals are streamed into LDS
+//     with 128-bit loads in which every wavefront instruction covers one contiguous
+//     KiB, marked non-temporal: the matrix is read once, so it must not displace x
+//     (or the y lines being written) from L2.  No x access happens while streaming.
+//   * rows are then walked out of LDS in ROW-major order: at step k every lane
+//     handles entry k of its own row.  For banded / stencil matrices the lanes of one
+//     gather instruction therefore read consecutive x addresses, which is what the
+//     per-CU L1 can serve at rate (an entry-major gather costs one L1 tag look-up
+//     per lane; measured on MI355X that look-up rate, not HBM, was the bound).
+//   * lanes per row L in {1,2,..,64} is chosen per tile from its mean fragment
+//     length (sub-wavefront-per-row), fragments longer than 16 L are handed to a
+//     whole wavefront (wavefront-per-row) with a cross-lane reduction.
+//   * a row that starts in tile t is written by tile t (plain/non-temporal store).
+//     The part of a row that spills into later tiles is written to head[t'] by those
 //     tiles and added in tile order by spmv_fixup: no atomics, so y is
 //     bit-reproducible run to run.
 //   * blockIdx -> tile is XCD-aware: the 8 XCDs (blocks b, b+8, ... share one)
 //     each take a contiguous eighth of the tiles, so the x window a row block
 //     gathers is cached in one XCD's L2 instead of all eight.
-// spmv_vector<LANES> (2..64 lanes per row; classic wavefront / sub-wavefront per
-//   row) is kept for matrices whose rows are uniformly long, where staging
-//   through LDS buys nothing.
+// spmv_vector<LANES> (2..64 lanes per row straight from global memory; classic
+//   wavefront / sub-wavefront per row) is kept as a selectable alternative.
 //
 // Algorithmic bytes per entry (f64, col_idx held as i32): 12 streamed + the row
 // terms 8 (row_ptr) + 8 (y) per row + 8 per x element.  HBM-bound; no MFMA.
@@ -32,7 +37,11 @@
 namespace samd {
 
 constexpr int kSpmvTile = (int)kPlanTile;  // entries per block
-constexpr int kLongFrag = 32;              // row fragments longer than this are reduced by a wavefront
+
+typedef unsigned int raw16 __attribute__((ext_vector_type(4)));  // one 128-bit load/store
+
+template <class V>
+__device__ __forceinline__ V ntload(const V *p) { return __builtin_nontemporal_load(p); }
 
 template <class T>
 struct alignas(sizeof(T) * 4) Vec4 {
@@ -51,67 +60,93 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
                                                              const T *__restrict__ x, T *__restrict__ y,
                                                              const int64_t *__restrict__ tile_lb,
                                                              T *__restrict__ head, int64_t nnz, int64_t ntiles) {
-  __shared__ T prod[TILE];
-  __shared__ int longrows[TILE / kLongFrag + 2];
+  __shared__ __attribute__((aligned(16))) T sval[TILE];
+  __shared__ __attribute__((aligned(16))) I scol[TILE];
+  __shared__ int longrows[TILE / 16 + 2];
   __shared__ int nlong;
 
   const int tid = threadIdx.x;
   const int64_t t = xcd_remap(blockIdx.x, ntiles);
   const int64_t base = t * TILE;
   const int cnt = (int)((nnz - base) < (int64_t)TILE ? (nnz - base) : (int64_t)TILE);
+  const int64_t lb0 = tile_lb[t], lb1 = tile_lb[t + 1];
 
-  // ---- phase 1: stream the tile, gather x, products to LDS
-  constexpr int ITERS = TILE / (kBlock * 4);
-  const I *cbase = col + base;
-  const T *vbase = val + base;
-  Vec4<I> c[ITERS];
-  Vec4<T> a[ITERS];
+  // ---- phase 1: stream the tile into LDS (line-dense, non-temporal)
+  constexpr int CV = TILE * (int)sizeof(I) / (16 * kBlock);
+  constexpr int VV = TILE * (int)sizeof(T) / (16 * kBlock);
+  static_assert(CV >= 1 && VV >= 1, "tile too small for 128-bit loads");
+  if (cnt == TILE) {
+    raw16 c[CV], a[VV];
+    const raw16 *cp = reinterpret_cast<const raw16 *>(col + base);
+    const raw16 *vp = reinterpret_cast<const raw16 *>(val + base);
 #pragma unroll
-  for (int it = 0; it < ITERS; it++) {
-    const int e = (it * kBlock + tid) * 4;
-    if (e + 4 <= cnt) {
-      c[it] = *reinterpret_cast<const Vec4<I> *>(cbase + e);
-      a[it] = *reinterpret_cast<const Vec4<T> *>(vbase + e);
-    } else {
+    for (int it = 0; it < CV; it++) c[it] = ntload(cp + it * kBlock + tid);
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const bool ok = e + q < cnt;
-        c[it].v[q] = ok ? cbase[e + q] : (I)0;
-        a[it].v[q] = ok ? vbase[e + q] : (T)0;
-      }
+    for (int it = 0; it < VV; it++) a[it] = ntload(vp + it * kBlock + tid);
+#pragma unroll
+    for (int it = 0; it < CV; it++) reinterpret_cast<raw16 *>(scol)[it * kBlock + tid] = c[it];
+#pragma unroll
+    for (int it = 0; it < VV; it++) reinterpret_cast<raw16 *>(sval)[it * kBlock + tid] = a[it];
+  } else {
+    for (int e = tid; e < cnt; e += kBlock) {
+      scol[e] = col[base + e];
+      sval[e] = val[base + e];
     }
   }
+
+  // ---- rows of this tile: the candidate head row (lb0-1) and the rows that start here
+  const int64_t rfirst = lb0 > 0 ? lb0 - 1 : 0;
+  const int nrows = (int)(lb1 - rfirst);
+  int L = 1;  // lanes per row, from the mean fragment length (uniform over the block)
+  {
+    const int avg4 = cnt / (nrows > 0 ? nrows : 1) / 4;
+    while (L < 64 && L * 2 <= avg4) L *= 2;
+  }
   if (tid == 0) nlong = 0;
-#pragma unroll
-  for (int it = 0; it < ITERS; it++) {
-    const int e = (it * kBlock + tid) * 4;
-    Vec4<T> p;
-#pragma unroll
-    for (int q = 0; q < 4; q++) p.v[q] = (e + q < cnt) ? (T)(a[it].v[q] * x[c[it].v[q]]) : (T)0;
-    *reinterpret_cast<Vec4<T> *>(&prod[e]) = p;
+  const int grp = tid / L, sub = tid & (L - 1), ngrp = kBlock / L;
+  int64_t rs0 = 0, re0 = 0;  // first row's bounds, requested before the barrier
+  if (grp < nrows) {
+    rs0 = ntload(&row_ptr[rfirst + grp]);
+    re0 = ntload(&row_ptr[rfirst + grp + 1]);
   }
   __syncthreads();
 
-  // ---- phase 2: one lane per row fragment
-  const int64_t lb0 = tile_lb[t], lb1 = tile_lb[t + 1];
-  const bool has_head = lb0 > 0 && row_ptr[lb0] > base;
-  const int64_t rfirst = lb0 - (has_head ? 1 : 0);
-  const int nrows = (int)(lb1 - rfirst);
-  for (int j = tid; j < nrows; j += kBlock) {
+  // ---- phase 2: L lanes per row fragment, row-major gather of x
+  const int64_t lim = base + cnt;
+  for (int j = grp; j < nrows; j += ngrp) {
     const int64_t r = rfirst + j;
-    const int64_t rs = row_ptr[r], re = row_ptr[r + 1];
+    int64_t rs, re;
+    if (j == grp) { rs = rs0; re = re0; }
+    else { rs = ntload(&row_ptr[r]); re = ntload(&row_ptr[r + 1]); }
+    if (r < lb0 && re <= base) continue;  // candidate head row does not reach this tile
     const int s = (int)((rs > base ? rs : base) - base);
-    const int64_t lim = base + cnt;
     const int e = (int)((re < lim ? re : lim) - base);
-    if (e - s > kLongFrag) {
-      const int slot = atomicAdd(&nlong, 1);
-      longrows[slot] = j;
+    if (e - s > 16 * L) {
+      if (sub == 0) {
+        const int slot = atomicAdd(&nlong, 1);
+        longrows[slot] = j;
+      }
       continue;
     }
     T acc = (T)0;
-    for (int q = s; q < e; q++) acc = (T)(acc + prod[q]);
-    if (rs >= base) y[r] = acc;
-    else head[t] = acc;
+    for (int q = s + sub; q < e; q += 8 * L) {
+      T xv[8], av[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int qq = q + u * L;
+        const bool ok = qq < e;
+        const I cc = scol[ok ? qq : s];
+        av[u] = ok ? sval[qq] : (T)0;
+        xv[u] = ok ? x[cc] : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) acc = (T)(acc + (T)(av[u] * xv[u]));
+    }
+    for (int d = L >> 1; d >= 1; d >>= 1) acc = (T)(acc + wshfl_xor(acc, d));
+    if (sub == 0) {
+      if (rs >= base) __builtin_nontemporal_store(acc, &y[r]);
+      else head[t] = acc;
+    }
   }
   __syncthreads();
 
@@ -122,10 +157,21 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
     const int64_t r = rfirst + longrows[i];
     const int64_t rs = row_ptr[r], re = row_ptr[r + 1];
     const int s = (int)((rs > base ? rs : base) - base);
-    const int64_t lim = base + cnt;
     const int e = (int)((re < lim ? re : lim) - base);
     T acc = (T)0;
-    for (int q = s + lane; q < e; q += 64) acc = (T)(acc + prod[q]);
+    for (int q = s + lane; q < e; q += 4 * 64) {
+      T xv[4], av[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int qq = q + u * 64;
+        const bool ok = qq < e;
+        const I cc = scol[ok ? qq : s];
+        av[u] = ok ? sval[qq] : (T)0;
+        xv[u] = ok ? x[cc] : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc = (T)(acc + (T)(av[u] * xv[u]));
+    }
     acc = wave_reduce(acc, OpAdd());
     if (lane == 0) {
       if (rs >= base) y[r] = acc;
