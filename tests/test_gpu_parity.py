@@ -342,3 +342,14 @@ def test_wide_col_option_keeps_parity(ctx):
         close(M.sr.smm(A, B), O.sr_smm(Ao, B), "f64")
     finally:
         ctx.set_option("wide_col", 0)
+
+
+def test_c_harness_written_against_generated_api(ctx):
+    """integration/harness_example.c uses only the generated-library convention."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "integration", "harness_example")
+    assert os.path.exists(exe), "build first (__graft_entry__.build)"
+    out = subprocess.run([exe], capture_output=True, timeout=100)
+    assert out.returncode == 0, out.stderr.decode()
+    assert b"harness ok" in out.stdout
