@@ -904,7 +904,7 @@ int main(int argc, char **argv) {
   vs.push_back({"shipped stream (spmv.hpp) 1024", [&] {
                   hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024>), dim3((unsigned)nt1k), dim3(256), 0, st,
                                      (const int64_t *)row_ptr, (const int32_t *)col, (const double *)val,
-                                     (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k);
+                                     (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k, 0);
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, 1024>), dim3((unsigned)((nt1k - 1 + 255) / 256)),
                                      dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)lb1k,
                                      (const double *)hd1k, y, nt1k);
@@ -912,7 +912,7 @@ int main(int argc, char **argv) {
   vs.push_back({"shipped, no fixup launch", [&] {
                   hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024>), dim3((unsigned)nt1k), dim3(256), 0, st,
                                      (const int64_t *)row_ptr, (const int32_t *)col, (const double *)val,
-                                     (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k);
+                                     (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k, 0);
                 }, false, {}});
   vs.push_back({"stream ceiling (same bytes)", [&] {
                   hipLaunchKernelGGL(stream_ceiling, dim3(2048), dim3(256), 0, st, (const int4 *)col,

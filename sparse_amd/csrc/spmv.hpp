@@ -59,7 +59,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
                                                              const I *__restrict__ col, const T *__restrict__ val,
                                                              const T *__restrict__ x, T *__restrict__ y,
                                                              const int64_t *__restrict__ tile_lb,
-                                                             T *__restrict__ head, int64_t nnz, int64_t ntiles) {
+                                                             T *__restrict__ head, int64_t nnz, int64_t ntiles,
+                                                             int force_lanes) {
   __shared__ __attribute__((aligned(16))) T sval[TILE];
   __shared__ __attribute__((aligned(16))) I scol[TILE];
   __shared__ int longrows[TILE / 16 + 2];
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
   {
     const int avg4 = cnt / (nrows > 0 ? nrows : 1) / 4;
     while (L < 64 && L * 2 <= avg4) L *= 2;
+    if (force_lanes > 0) L = force_lanes;  // test / tuning override (power of two <= 64)
   }
   if (tid == 0) nlong = 0;
   const int grp = tid / L, sub = tid & (L - 1), ngrp = kBlock / L;
@@ -225,9 +227,11 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
   if (algo == 0) algo = 1;
   if (algo == 1) {
     if (a->tile != kSpmvTile) return set_error(ctx, "spmv: plan tile mismatch");
+    int force = (int)ctx->opt_spmv_lanes;
+    if (force < 0 || force > 64 || (force & (force - 1))) return set_error(ctx, "spmv: spmv_lanes must be a power of two <= 64");
     hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile>), dim3((unsigned)a->ntiles), dim3(kBlock), 0, ctx->stream,
                        (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y, (const int64_t *)a->tile_lb,
-                       a->head, a->nnz, a->ntiles);
+                       a->head, a->nnz, a->ntiles, force);
     SAMD_LAUNCH_CHECK(ctx);
     if (a->ntiles > 1) {
       hipLaunchKernelGGL((spmv_fixup_kernel<T, kSpmvTile>), dim3((unsigned)cdiv(a->ntiles - 1, kBlock)), dim3(kBlock),

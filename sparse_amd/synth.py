@@ -183,3 +183,50 @@ def laplacian_2d_apply_device(g, x):
     Y[1:, :] -= X[:-1, :]
     Y[:-1, :] -= X[1:, :]
     return Y.reshape(-1)
+
+
+def random_uniform_coo_device(n, m, nnz0, device, dtype="f64", seed=42):
+    """C1/C5 shape on the device (torch's Philox generator; not the splitmix stream)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    r = torch.randint(0, n, (nnz0,), generator=g, device=device, dtype=torch.int64)
+    c = torch.randint(0, m, (nnz0,), generator=g, device=device, dtype=torch.int64)
+    tdt = {"f64": torch.float64, "f32": torch.float32}[dtype]
+    v = torch.rand(nnz0, generator=g, device=device, dtype=tdt) + 0.5
+    return r, c, v
+
+
+def rmat_coo_device(scale, edge_factor, device, dtype="f32", seed=42, probs=(0.57, 0.19, 0.19, 0.05)):
+    """C3 shape on the device: RMAT, one quadrant draw per bit level."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cnt = (1 << scale) * edge_factor
+    r = torch.zeros(cnt, dtype=torch.int64, device=device)
+    c = torch.zeros(cnt, dtype=torch.int64, device=device)
+    a, b, cc, _ = probs
+    for _ in range(scale):
+        u = torch.rand(cnt, generator=g, device=device, dtype=torch.float32)
+        r = (r << 1) | (u >= a + b).to(torch.int64)
+        c = (c << 1) | (((u >= a) & (u < a + b)) | (u >= a + b + cc)).to(torch.int64)
+        del u
+    tdt = {"f64": torch.float64, "f32": torch.float32}[dtype]
+    v = torch.rand(cnt, generator=g, device=device, dtype=tdt) + 0.5
+    return r, c, v
+
+
+def banded_coo_device(n, half_bw, device, dtype="f64", seed=42):
+    """C4 shape on the device: 2*half_bw+1 entries per row, clipped at the edges, row-major."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    i = torch.arange(n, dtype=torch.int64, device=device)
+    d = torch.arange(-half_bw, half_bw + 1, dtype=torch.int64, device=device)
+    c = (i[:, None] + d[None, :]).reshape(-1)
+    r = i[:, None].expand(n, 2 * half_bw + 1).reshape(-1)
+    ok = (c >= 0) & (c < n)
+    r, c = r[ok].contiguous(), c[ok].contiguous()
+    tdt = {"f64": torch.float64, "f32": torch.float32}[dtype]
+    v = torch.rand(r.numel(), generator=g, device=device, dtype=tdt) + 0.5
+    return r, c, v
