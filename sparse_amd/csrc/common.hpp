@@ -112,6 +112,7 @@ struct futhark_context {
   int64_t opt_spmv_lanes = 0;
   int64_t opt_wide_col = 0;
   int64_t opt_spmv_tile = 0;
+  int64_t opt_spmm_algo = 0;
   // statistics for futhark_context_report
   int64_t n_entries = 0;
 };

@@ -12,7 +12,7 @@
 // (~2.4 flop/B at k=64, below the f64 ridge).
 #pragma once
 
-#include "assembly.hpp"
+#include "spmv.hpp"
 
 namespace samd {
 
@@ -49,20 +49,294 @@ __global__ __launch_bounds__(kBlock) void spmm_rowpanel_kernel(const int64_t *__
   }
 }
 
+// spmm_stream: the SpMV streaming structure with a 64-wide strip of C per row.
+//   * same nnz-balanced tiles, col_idx/vals staged in LDS by line-dense non-temporal loads,
+//     the tile's row bounds cached in LDS;
+//   * a block is 16 slots x 16 lanes: a slot owns one row at a time, each of its 16 lanes four
+//     adjacent columns of the strip (one 32-B access for f64), so a wavefront instruction
+//     serves 4 rows x 64 columns and the per-entry index arithmetic is paid once per 4 FMAs;
+//     the 16 slots walk ADJACENT rows at the same time;
+//   * LDS-tiled row panel: when the tile's columns span at most kWinRows rows of B (banded /
+//     FEM matrices: the dense block of the RHS this row panel multiplies), that window of the
+//     strip is staged in LDS once with coalesced loads and every entry reads B from LDS; a B
+//     row is then fetched once per tile instead of once per entry (the per-CU L1 returns
+//     64 B/clk, so a 512-B row segment per entry caps the direct path near 34 TB/s chip-wide);
+//   * fragments longer than 64 entries are split over the 16 slots and combined by cross-lane
+//     adds + LDS;
+//   * rows crossing tiles: owner tile stores, later tiles store a k-wide head row, the
+//     fix-up kernel adds them in tile order (no atomics).
+constexpr int kWinRows = 72;    // rows of B (x 64 columns) staged per tile
+constexpr int kRowCache = 256;  // row bounds of the tile's first rows, read once into LDS
+
+__device__ __forceinline__ int rel_clamp(int64_t v, int64_t base, int tile) {
+  const int64_t d = v - base;
+  return d < -1 ? -1 : (d > tile + 1 ? tile + 1 : (int)d);
+}
+
+template <class T, class I, int TILE, bool VEC>
+__global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__restrict__ row_ptr,
+                                                             const I *__restrict__ col, const T *__restrict__ val,
+                                                             const T *__restrict__ B, T *__restrict__ C,
+                                                             const int64_t *__restrict__ tile_lb,
+                                                             T *__restrict__ head, int64_t nnz, int64_t ntiles,
+                                                             int64_t k) {
+  __shared__ __attribute__((aligned(16))) T sval[TILE];
+  __shared__ __attribute__((aligned(16))) I scol[TILE];
+  __shared__ __attribute__((aligned(32))) T sB[kWinRows * 64];
+  __shared__ __attribute__((aligned(32))) T part[kWaves][64];
+  __shared__ long long swin[2 * kWaves];
+  __shared__ int srel[kRowCache + 1];  // row bounds relative to the tile, clamped to [-1, TILE+1]
+  __shared__ int longrows[TILE / 64 + 2];
+  __shared__ int nlong;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = tid >> 4, cg = tid & 15;
+  const int64_t t = xcd_remap(blockIdx.x, ntiles);
+  const int64_t base = t * TILE;
+  const int cnt = (int)((nnz - base) < (int64_t)TILE ? (nnz - base) : (int64_t)TILE);
+  const int64_t lb0 = tile_lb[t], lb1 = tile_lb[t + 1];
+  constexpr int CV = TILE * (int)sizeof(I) / (16 * kBlock);
+  constexpr int VV = TILE * (int)sizeof(T) / (16 * kBlock);
+  if (cnt == TILE) {
+    raw16 c[CV], a[VV];
+    const raw16 *cp = reinterpret_cast<const raw16 *>(col + base);
+    const raw16 *vp = reinterpret_cast<const raw16 *>(val + base);
+#pragma unroll
+    for (int it = 0; it < CV; it++) c[it] = ntload(cp + it * kBlock + tid);
+#pragma unroll
+    for (int it = 0; it < VV; it++) a[it] = ntload(vp + it * kBlock + tid);
+#pragma unroll
+    for (int it = 0; it < CV; it++) reinterpret_cast<raw16 *>(scol)[it * kBlock + tid] = c[it];
+#pragma unroll
+    for (int it = 0; it < VV; it++) reinterpret_cast<raw16 *>(sval)[it * kBlock + tid] = a[it];
+  } else {
+    for (int e = tid; e < cnt; e += kBlock) {
+      scol[e] = col[base + e];
+      sval[e] = val[base + e];
+    }
+  }
+  if (tid == 0) nlong = 0;
+  const int64_t rfirst = lb0 > 0 ? lb0 - 1 : 0;
+  const int nrows = (int)(lb1 - rfirst);
+  for (int jr = tid; jr <= nrows && jr <= kRowCache; jr += kBlock) srel[jr] = rel_clamp(row_ptr[rfirst + jr], base, TILE);
+  __syncthreads();
+
+  // column window of the tile
+  long long cmin = 0x7fffffffffffffffLL, cmax = -1;
+  for (int e = tid; e < cnt; e += kBlock) {
+    const long long c = (long long)scol[e];
+    cmin = c < cmin ? c : cmin;
+    cmax = c > cmax ? c : cmax;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const long long a = wshfl_xor(cmin, d), b = wshfl_xor(cmax, d);
+    cmin = a < cmin ? a : cmin;
+    cmax = b > cmax ? b : cmax;
+  }
+  if (lane == 0) { swin[wave] = cmin; swin[kWaves + wave] = cmax; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    cmin = swin[w] < cmin ? swin[w] : cmin;
+    cmax = swin[kWaves + w] > cmax ? swin[kWaves + w] : cmax;
+  }
+  const int wrows = (int)(cmax - cmin + 1 <= kWinRows ? cmax - cmin + 1 : 0);  // 0: no window
+
+  // B[c][j0..j0+3] for this lane: from the LDS window, or straight from memory
+  auto loadB = [&](int64_t c, int64_t j0, bool ok, T (&b)[4]) {
+    if (wrows > 0) {
+      const Vec4<T> v = *reinterpret_cast<const Vec4<T> *>(&sB[(int)(c - cmin) * 64 + cg * 4]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) b[u] = v.v[u];
+    } else if (VEC) {
+      Vec4<T> v;
+      if (ok && j0 < k) v = *reinterpret_cast<const Vec4<T> *>(&B[c * k + j0]);
+      else { v.v[0] = v.v[1] = v.v[2] = v.v[3] = (T)0; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) b[u] = v.v[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; u++) b[u] = (ok && j0 + u < k) ? B[c * k + j0 + u] : (T)0;
+    }
+  };
+  auto storeRow = [&](T *dst, int64_t j0, const T (&acc)[4], bool nt) {
+    if (VEC) {
+      if (j0 < k) {
+        Vec4<T> v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) v.v[u] = acc[u];
+        if (nt) {
+          const raw16 *pv = reinterpret_cast<const raw16 *>(&v);
+          raw16 *pd = reinterpret_cast<raw16 *>(dst + j0);
+#pragma unroll
+          for (int i = 0; i < (int)(sizeof(Vec4<T>) / 16); i++) __builtin_nontemporal_store(pv[i], pd + i);
+        }
+        else *reinterpret_cast<Vec4<T> *>(dst + j0) = v;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (j0 + u < k) dst[j0 + u] = acc[u];
+    }
+  };
+
+  for (int64_t cb = 0; cb < k; cb += 64) {
+    const int64_t j = cb + lane;
+    const int64_t j0 = cb + cg * 4;
+    if (wrows > 0) {
+      if (cb > 0) __syncthreads();  // previous strip's readers are done with sB
+      for (int w0 = wave; w0 < wrows; w0 += kWaves * 8) {  // 8 row segments in flight per wavefront
+        T tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int w = w0 + u * kWaves;
+          tmp[u] = (w < wrows && j < k) ? B[(cmin + w) * k + j] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int w = w0 + u * kWaves;
+          if (w < wrows) sB[w * 64 + lane] = tmp[u];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- one slot (16 lanes x 4 columns) per row fragment, adjacent rows on the 16 slots
+    for (int jr = slot; jr < nrows; jr += 16) {
+      const int64_t r = rfirst + jr;
+      int rs, re;  // relative to the tile
+      if (jr < kRowCache) { rs = srel[jr]; re = srel[jr + 1]; }
+      else { rs = rel_clamp(row_ptr[r], base, TILE); re = rel_clamp(row_ptr[r + 1], base, TILE); }
+      if (r < lb0 && re <= 0) continue;
+      const int s = rs > 0 ? rs : 0;
+      const int e = re < cnt ? re : cnt;
+      if (e - s > 64) {
+        if (cb == 0 && cg == 0) {
+          const int sl = atomicAdd(&nlong, 1);
+          longrows[sl] = jr;
+        }
+        continue;
+      }
+      T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+      for (int q = s; q < e; q += 2) {
+        T b0[4], b1[4];
+        const bool ok1 = q + 1 < e;
+        const T a0 = sval[q], a1 = ok1 ? sval[q + 1] : (T)0;
+        loadB((int64_t)scol[q], j0, true, b0);
+        loadB((int64_t)scol[ok1 ? q + 1 : q], j0, ok1, b1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = (T)(acc[u] + (T)(a0 * b0[u]));
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = (T)(acc[u] + (T)(a1 * b1[u]));
+      }
+      storeRow(rs >= 0 ? C + r * k : head + t * k, j0, acc, rs >= 0);
+    }
+    __syncthreads();
+    // ---- long fragments: the 16 slots split the entries; partial strips meet via shuffles + LDS
+    const int nl = nlong;
+    for (int i = 0; i < nl; i++) {
+      const int64_t r = rfirst + longrows[i];
+      const int rs = rel_clamp(row_ptr[r], base, TILE), re = rel_clamp(row_ptr[r + 1], base, TILE);
+      const int s = rs > 0 ? rs : 0;
+      const int e = re < cnt ? re : cnt;
+      T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+      for (int q = s + slot; q < e; q += 32) {
+        T b0[4], b1[4];
+        const bool ok1 = q + 16 < e;
+        const T a0 = sval[q], a1 = ok1 ? sval[q + 16] : (T)0;
+        loadB((int64_t)scol[q], j0, true, b0);
+        loadB((int64_t)scol[ok1 ? q + 16 : q], j0, ok1, b1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = (T)(acc[u] + (T)(a0 * b0[u]));
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = (T)(acc[u] + (T)(a1 * b1[u]));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {  // the 4 slots of a wavefront hold the same columns 16 lanes apart
+        acc[u] = (T)(acc[u] + wshfl_xor(acc[u], 16));
+        acc[u] = (T)(acc[u] + wshfl_xor(acc[u], 32));
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) part[wave][cg * 4 + u] = acc[u];
+      }
+      __syncthreads();
+      if (tid < 64 && cb + tid < k) {
+        T sum = part[0][tid];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) sum = (T)(sum + part[w][tid]);
+        if (rs >= 0) C[r * k + cb + tid] = sum;
+        else head[t * k + cb + tid] = sum;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// one block per tile t >= 1: if t is the first spill of its head row, fold the k-wide heads
+template <class T, int TILE>
+__global__ __launch_bounds__(64) void spmm_fixup_kernel(const int64_t *__restrict__ row_ptr,
+                                                        const int64_t *__restrict__ tile_lb,
+                                                        const T *__restrict__ head, T *__restrict__ C,
+                                                        int64_t ntiles, int64_t k) {
+  const int64_t t = (int64_t)blockIdx.x + 1;
+  if (t >= ntiles) return;
+  const int64_t lb = tile_lb[t];
+  if (lb == 0) return;
+  const int64_t base = t * TILE;
+  const int64_t r = lb - 1;
+  const int64_t re = row_ptr[lb];
+  if (re <= base) return;
+  if (row_ptr[r] < base - TILE) return;
+  for (int64_t j = threadIdx.x; j < k; j += 64) {
+    T acc = C[r * k + j];
+    for (int64_t u = t; u < ntiles && u * TILE < re; u++) acc = (T)(acc + head[u * k + j]);
+    C[r * k + j] = acc;
+  }
+}
+
+template <class T, class I>
+int spmm_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T *B, int64_t k, T *C) {
+  if (ctx->opt_spmm_algo == 2) {
+    int64_t want = cdiv(a->n * 64, kBlock);
+    const int64_t cap = (int64_t)ctx->num_cu * 64;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL((spmm_rowpanel_kernel<T, I>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                       (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C, a->n, k);
+    SAMD_LAUNCH_CHECK(ctx);
+    return 0;
+  }
+  if (a->tile != kSpmvTile) return set_error(ctx, "spmm: plan tile mismatch");
+  Tmp<T> head(ctx);
+  SAMD_TRY(head.get(a->ntiles * k));
+  // 4-column accesses need 4-element alignment of every row of B and C (and of the head rows)
+  const bool vec = (k % 4 == 0) && ((uintptr_t)B % (sizeof(T) * 4) == 0) && ((uintptr_t)C % (sizeof(T) * 4) == 0);
+  if (vec)
+    hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, true>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
+                       ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C,
+                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k);
+  else
+    hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, false>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
+                       ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C,
+                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k);
+  SAMD_LAUNCH_CHECK(ctx);
+  if (a->ntiles > 1) {
+    hipLaunchKernelGGL((spmm_fixup_kernel<T, kSpmvTile>), dim3((unsigned)(a->ntiles - 1)), dim3(64), 0, ctx->stream,
+                       (const int64_t *)a->row_ptr, (const int64_t *)a->tile_lb, (const T *)head.p, C, a->ntiles, k);
+    SAMD_LAUNCH_CHECK(ctx);
+  }
+  return 0;
+}
+
 template <class T>
 int spmm(futhark_context *ctx, const CsrBody<T> *a, const T *B, int64_t k, T *C) {
   if (a->n == 0 || k == 0) return 0;
-  int64_t want = cdiv(a->n * 64, kBlock);
-  const int64_t cap = (int64_t)ctx->num_cu * 64;
-  const unsigned grid = (unsigned)(want < cap ? want : cap);
-  if (a->col32)
-    hipLaunchKernelGGL((spmm_rowpanel_kernel<T, int32_t>), dim3(grid), dim3(kBlock), 0, ctx->stream,
-                       (const int64_t *)a->row_ptr, (const int32_t *)a->col32, (const T *)a->vals, B, C, a->n, k);
-  else
-    hipLaunchKernelGGL((spmm_rowpanel_kernel<T, int64_t>), dim3(grid), dim3(kBlock), 0, ctx->stream,
-                       (const int64_t *)a->row_ptr, (const int64_t *)a->col64, (const T *)a->vals, B, C, a->n, k);
-  SAMD_LAUNCH_CHECK(ctx);
-  return 0;
+  if (a->nnz == 0) {
+    SAMD_HIP(ctx, hipMemsetAsync(C, 0, sizeof(T) * (size_t)(a->n * k), ctx->stream));
+    return 0;
+  }
+  if (a->col32) return spmm_typed<T, int32_t>(ctx, a, a->col32, B, k, C);
+  return spmm_typed<T, int64_t>(ctx, a, a->col64, B, k, C);
 }
 
 // ------------------------------------------------------------------- smsmm

@@ -287,13 +287,22 @@ def test_constructors(ctx, dtype):
 
 @pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
 @pytest.mark.parametrize("k", [1, 8, 64, 100])
-def test_smm_matches_oracle(ctx, dtype, k):
+@pytest.mark.parametrize("algo", [0, 2])
+def test_smm_matches_oracle(ctx, dtype, k, algo):
     O, M = Oracle(dtype), mk(ctx, dtype)
-    n, m = 900, 700
-    r, c, v = skewed_coo(n, m, dtype, 31)
-    A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
-    B = synth.uniform_values(32, m * k, dtype).reshape(m, k)
-    close(M.sr.smm(A, B), O.sr_smm(Ao, B), dtype)
+    ctx.set_option("spmm_algo", algo)
+    try:
+        for n, m, gen in ((900, 700, lambda: skewed_coo(900, 700, dtype, 31)),
+                          (3000, 3000, lambda: synth.banded_coo(3000, 13, dtype)),
+                          (5, 4000, lambda: random_coo(5, 4000, 9000, dtype, seed=33))):
+            r, c, v = gen()
+            A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
+            B = synth.uniform_values(32, m * k, dtype).reshape(m, k)
+            close(M.sr.smm(A, B), O.sr_smm(Ao, B), dtype)
+        Z = M.sr.zero(7, 5)
+        assert np.array_equal(M.sr.smm(Z, np.ones((5, k), NP[dtype])).numpy(), np.zeros((7, k), NP[dtype]))
+    finally:
+        ctx.set_option("spmm_algo", 0)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "i32"])
