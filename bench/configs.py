@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--compare", action="store_true", help="also time torch.sparse (rocSPARSE) CSR SpMV as a comparator")
     args = ap.parse_args()
     import torch
@@ -46,6 +47,8 @@ def main():
         ctx.set_option("spmv_algo", args.algo)
     if args.lanes:
         ctx.set_option("spmv_lanes", args.lanes)
+    if args.ablate:
+        ctx.set_option("ablate", args.ablate)
 
     def run(name, dtype, n, m, gen, spmm_k=0):
         vb = 8 if dtype == "f64" else 4

@@ -386,6 +386,7 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_lanes")) ctx->opt_spmv_lanes = value;
   else if (!strcmp(key, "wide_col")) ctx->opt_wide_col = value;
   else if (!strcmp(key, "spmm_algo")) ctx->opt_spmm_algo = value;
+  else if (!strcmp(key, "ablate")) ctx->opt_ablate = value;
   else return set_error(ctx, "unknown option '%s'", key);
   return 0;
 }

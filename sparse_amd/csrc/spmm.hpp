@@ -79,10 +79,11 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
                                                              const T *__restrict__ B, T *__restrict__ C,
                                                              const int64_t *__restrict__ tile_lb,
                                                              T *__restrict__ head, int64_t nnz, int64_t ntiles,
-                                                             int64_t k) {
+                                                             int64_t k, int ablate) {
   __shared__ __attribute__((aligned(16))) T sval[TILE];
   __shared__ __attribute__((aligned(16))) I scol[TILE];
-  __shared__ __attribute__((aligned(32))) T sB[kWinRows * 64];
+  __shared__ raw16 sBv[kWinRows * 64 * sizeof(T) / 16];  // B window, addressed in 16-byte units
+  T *sB = reinterpret_cast<T *>(sBv);
   __shared__ __attribute__((aligned(32))) T part[kWaves][64];
   __shared__ long long swin[2 * kWaves];
   __shared__ int srel[kRowCache + 1];  // row bounds relative to the tile, clamped to [-1, TILE+1]
@@ -143,60 +144,93 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
   }
   const int wrows = (int)(cmax - cmin + 1 <= kWinRows ? cmax - cmin + 1 : 0);  // 0: no window
 
-  // B[c][j0..j0+3] for this lane: from the LDS window, or straight from memory
-  auto loadB = [&](int64_t c, int64_t j0, bool ok, T (&b)[4]) {
-    if (wrows > 0) {
-      const Vec4<T> v = *reinterpret_cast<const Vec4<T> *>(&sB[(int)(c - cmin) * 64 + cg * 4]);
+  constexpr int P = 16 / (int)sizeof(T);  // elements per 16-byte piece
+  constexpr int P16 = P;
+  constexpr int H = 4 / P;
+  // In window mode the staged column ids become offsets of B's row inside sB, in 16-byte units.
+  if (wrows > 0) {
+    for (int e = tid; e < cnt; e += kBlock) scol[e] = (I)(((long long)scol[e] - cmin) * (64 / P16));
+    __syncthreads();
+  }
+
+  // Lane cg of a slot owns 4 columns of the 64-wide strip as 16-byte pieces: piece h holds
+  // columns h*16*P + cg*P .. +P-1 (P = 16 B / sizeof(T)), so the 16 lanes of a slot touch 256
+  // contiguous bytes per access: coalesced in memory, conflict-free in LDS.
+  auto loadB = [&](int64_t c, int64_t cb, bool ok, T (&b)[4]) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) b[u] = v.v[u];
-    } else if (VEC) {
-      Vec4<T> v;
-      if (ok && j0 < k) v = *reinterpret_cast<const Vec4<T> *>(&B[c * k + j0]);
-      else { v.v[0] = v.v[1] = v.v[2] = v.v[3] = (T)0; }
+    for (int h = 0; h < H; h++) {
+      const int jl = h * 16 * P + cg * P;  // first column of the piece, relative to the strip
+      if (wrows > 0) {
+        const raw16 v = sBv[(int)c + h * 16 + cg];
+        const T *pv = reinterpret_cast<const T *>(&v);
 #pragma unroll
-      for (int u = 0; u < 4; u++) b[u] = v.v[u];
-    } else {
+        for (int p = 0; p < P; p++) b[h * P + p] = pv[p];
+      } else if (VEC) {
+        raw16 v = {0u, 0u, 0u, 0u};
+        if (ok && cb + jl < k) v = *reinterpret_cast<const raw16 *>(&B[c * k + cb + jl]);
+        const T *pv = reinterpret_cast<const T *>(&v);
 #pragma unroll
-      for (int u = 0; u < 4; u++) b[u] = (ok && j0 + u < k) ? B[c * k + j0 + u] : (T)0;
+        for (int p = 0; p < P; p++) b[h * P + p] = pv[p];
+      } else {
+#pragma unroll
+        for (int p = 0; p < P; p++) b[h * P + p] = (ok && cb + jl + p < k) ? B[c * k + cb + jl + p] : (T)0;
+      }
     }
   };
-  auto storeRow = [&](T *dst, int64_t j0, const T (&acc)[4], bool nt) {
-    if (VEC) {
-      if (j0 < k) {
-        Vec4<T> v;
+  auto storeRow = [&](T *dst, int64_t cb, const T (&acc)[4], bool nt) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) v.v[u] = acc[u];
-        if (nt) {
-          const raw16 *pv = reinterpret_cast<const raw16 *>(&v);
-          raw16 *pd = reinterpret_cast<raw16 *>(dst + j0);
+    for (int h = 0; h < H; h++) {
+      const int64_t j0 = cb + h * 16 * P + cg * P;
+      if (VEC) {
+        if (j0 < k) {
+          raw16 v;
+          T *pv = reinterpret_cast<T *>(&v);
 #pragma unroll
-          for (int i = 0; i < (int)(sizeof(Vec4<T>) / 16); i++) __builtin_nontemporal_store(pv[i], pd + i);
+          for (int p = 0; p < P; p++) pv[p] = acc[h * P + p];
+          if (nt) __builtin_nontemporal_store(v, reinterpret_cast<raw16 *>(dst + j0));
+          else *reinterpret_cast<raw16 *>(dst + j0) = v;
         }
-        else *reinterpret_cast<Vec4<T> *>(dst + j0) = v;
-      }
-    } else {
+      } else {
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (j0 + u < k) dst[j0 + u] = acc[u];
+        for (int p = 0; p < P; p++)
+          if (j0 + p < k) dst[j0 + p] = acc[h * P + p];
+      }
     }
   };
 
   for (int64_t cb = 0; cb < k; cb += 64) {
     const int64_t j = cb + lane;
-    const int64_t j0 = cb + cg * 4;
     if (wrows > 0) {
       if (cb > 0) __syncthreads();  // previous strip's readers are done with sB
-      for (int w0 = wave; w0 < wrows; w0 += kWaves * 8) {  // 8 row segments in flight per wavefront
-        T tmp[8];
+      if (VEC) {
+        // the whole window in one round of 16-byte pieces: every load is in flight at once
+        constexpr int PPR = 64 / P;                                  // pieces per row of the strip
+        constexpr int NP = (kWinRows * PPR + kBlock - 1) / kBlock;   // pieces per thread
+        raw16 tmp[NP];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int w = w0 + u * kWaves;
-          tmp[u] = (w < wrows && j < k) ? B[(cmin + w) * k + j] : (T)0;
+        for (int u = 0; u < NP; u++) {
+          const int pc = u * kBlock + tid, w = pc / PPR, jp = (pc % PPR) * P;
+          tmp[u] = raw16{0u, 0u, 0u, 0u};
+          if (w < wrows && cb + jp < k && !(ablate & 4)) tmp[u] = *reinterpret_cast<const raw16 *>(&B[(cmin + w) * k + cb + jp]);
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const int w = w0 + u * kWaves;
-          if (w < wrows) sB[w * 64 + lane] = tmp[u];
+        for (int u = 0; u < NP; u++) {
+          const int pc = u * kBlock + tid;
+          if (pc < wrows * PPR) sBv[pc] = tmp[u];
+        }
+      } else {
+        for (int w0 = wave; w0 < wrows; w0 += kWaves * 8) {  // 8 row segments in flight per wavefront
+          T tmp[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int w = w0 + u * kWaves;
+            tmp[u] = (w < wrows && j < k) ? B[(cmin + w) * k + j] : (T)0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int w = w0 + u * kWaves;
+            if (w < wrows) sB[w * 64 + lane] = tmp[u];
+          }
         }
       }
       __syncthreads();
@@ -218,18 +252,24 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
         continue;
       }
       T acc[4] = {(T)0, (T)0, (T)0, (T)0};
-      for (int q = s; q < e; q += 2) {
-        T b0[4], b1[4];
-        const bool ok1 = q + 1 < e;
-        const T a0 = sval[q], a1 = ok1 ? sval[q + 1] : (T)0;
-        loadB((int64_t)scol[q], j0, true, b0);
-        loadB((int64_t)scol[ok1 ? q + 1 : q], j0, ok1, b1);
+      constexpr int U = 4;  // entries in flight per slot: LDS index -> LDS window is a dependent chain
+      for (int q = s; q < ((ablate & 1) ? s : e); q += U) {
+        T a[U], b[U][4];
+        int64_t c[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] = (T)(acc[u] + (T)(a0 * b0[u]));
+        for (int u = 0; u < U; u++) {
+          const bool ok = q + u < e;
+          c[u] = (int64_t)scol[ok ? q + u : q];
+          a[u] = ok ? sval[q + u] : (T)0;
+        }
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] = (T)(acc[u] + (T)(a1 * b1[u]));
+        for (int u = 0; u < U; u++) loadB(c[u], cb, q + u < e, b[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) acc[v] = (T)(acc[v] + (T)(a[u] * b[u][v]));
       }
-      storeRow(rs >= 0 ? C + r * k : head + t * k, j0, acc, rs >= 0);
+      if (!(ablate & 2)) storeRow(rs >= 0 ? C + r * k : head + t * k, cb, acc, rs >= 0);
     }
     __syncthreads();
     // ---- long fragments: the 16 slots split the entries; partial strips meet via shuffles + LDS
@@ -244,8 +284,8 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
         T b0[4], b1[4];
         const bool ok1 = q + 16 < e;
         const T a0 = sval[q], a1 = ok1 ? sval[q + 16] : (T)0;
-        loadB((int64_t)scol[q], j0, true, b0);
-        loadB((int64_t)scol[ok1 ? q + 16 : q], j0, ok1, b1);
+        loadB((int64_t)scol[q], cb, true, b0);
+        loadB((int64_t)scol[ok1 ? q + 16 : q], cb, ok1, b1);
 #pragma unroll
         for (int u = 0; u < 4; u++) acc[u] = (T)(acc[u] + (T)(a0 * b0[u]));
 #pragma unroll
@@ -258,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
       }
       if (lane < 16) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) part[wave][cg * 4 + u] = acc[u];
+        for (int u = 0; u < 4; u++) part[wave][(u / P) * 16 * P + cg * P + (u % P)] = acc[u];
       }
       __syncthreads();
       if (tid < 64 && cb + tid < k) {
@@ -309,16 +349,16 @@ int spmm_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
   if (a->tile != kSpmvTile) return set_error(ctx, "spmm: plan tile mismatch");
   Tmp<T> head(ctx);
   SAMD_TRY(head.get(a->ntiles * k));
-  // 4-column accesses need 4-element alignment of every row of B and C (and of the head rows)
-  const bool vec = (k % 4 == 0) && ((uintptr_t)B % (sizeof(T) * 4) == 0) && ((uintptr_t)C % (sizeof(T) * 4) == 0);
+  // 16-byte accesses need every row of B, C and of the head rows 16-byte aligned
+  const bool vec = ((k * sizeof(T)) % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0);
   if (vec)
     hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, true>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
                        ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C,
-                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k);
+                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, (int)ctx->opt_ablate);
   else
     hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, false>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
                        ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C,
-                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k);
+                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, (int)ctx->opt_ablate);
   SAMD_LAUNCH_CHECK(ctx);
   if (a->ntiles > 1) {
     hipLaunchKernelGGL((spmm_fixup_kernel<T, kSpmvTile>), dim3((unsigned)(a->ntiles - 1)), dim3(64), 0, ctx->stream,

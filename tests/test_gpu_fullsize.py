@@ -76,3 +76,21 @@ def test_c2_coo_roundtrip_is_idempotent(setup):
     A2 = M.sr.sparse(n, n, (r, c, v))
     for a, b in zip(A.fields(), A2.fields()):
         assert torch.equal(torch.as_tensor(a, device="cuda:0"), torch.as_tensor(b, device="cuda:0"))
+
+
+def test_dist_csr_single_rank_on_gpu():
+    """The row-sharded wrapper with a world of one: torch CUDA tensors in, the same kernel underneath."""
+    import torch
+    from sparse_amd import Context, mk_compressed, synth
+    from sparse_amd.distributed import DistCsr
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    M = mk_compressed("f64", ctx)
+    g = 512
+    n = g * g
+    r, c, v = synth.laplacian_2d_coo_device(g, "cuda:0")
+    D = DistCsr.from_local_coo(M, None, n, n, 0, n, r, c, v)
+    assert D.mode == "none" and D.x_len == n
+    D.x_own.copy_(synth.laplacian_x_device(0, n, "cuda:0"))
+    y = torch.as_tensor(D.smvm(), device="cuda:0")
+    assert torch.equal(y, synth.laplacian_2d_apply_rows(g, g, 0, n, "cuda:0"))
