@@ -6,7 +6,7 @@
 //   pack      (row, col) i64 pair -> one unsigned key (row << cbits | col), bounds
 //             check (the assert at :156) folded in                         [1 pass]
 //   sort      stable LSD radix sort on the significant key bits only, payload =
-//             source index (radix_sort.hpp)                        [<= 8 passes]
+//             the entry's value bits (radix_sort.hpp)               [<= 8 passes]
 //   heads     inclusive scan of the head flags key[i] != key[i-1] (:77-81) gives
 //             every run its output slot; the scan total is the merged count
 //   emit      one thread per element: run heads fold their run left to right in
@@ -89,7 +89,14 @@ struct HeadFlagIn {
   }
 };
 
-template <class K, class T, class I>
+template <class T> struct BitsOf;
+template <> struct BitsOf<double> { typedef uint64_t type; };
+template <> struct BitsOf<float> { typedef uint32_t type; };
+template <> struct BitsOf<int32_t> { typedef uint32_t type; };
+
+// INDIRECT: vals_in is in source order and perm[i] is the source of sorted entry i
+// (nullptr = identity); otherwise vals_in is already in key order.
+template <class K, class T, class I, bool INDIRECT>
 __global__ __launch_bounds__(kBlock) void merge_emit_kernel(const K *__restrict__ keys,
                                                             const uint32_t *__restrict__ perm,
                                                             const uint32_t *__restrict__ slot,  // inclusive head count
@@ -104,9 +111,10 @@ __global__ __launch_bounds__(kBlock) void merge_emit_kernel(const K *__restrict_
   const bool has_next = i + 1 < count;
   const K knext = has_next ? keys[i + 1] : (K)0;
   if (head) {
-    T acc = vals_in[perm[i]];
+    auto src = [&](int64_t q) -> int64_t { return (INDIRECT && perm) ? (int64_t)perm[q] : q; };
+    T acc = vals_in[src(i)];
     if (has_next && knext == k) {
-      for (int64_t j = i + 1; j < count && keys[j] == k; j++) acc = (T)(acc + vals_in[perm[j]]);
+      for (int64_t j = i + 1; j < count && keys[j] == k; j++) acc = (T)(acc + vals_in[src(j)]);
     }
     col_out[s - 1] = (I)(k & minor_mask);
     vals_out[s - 1] = acc;
@@ -163,17 +171,24 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
 
   int64_t merged = 0;
   if (count > 0) {
+    constexpr bool kIndirect = sizeof(T) > 4;  // see radix_sort.hpp, "Payload"
     Tmp<K> keys_b(ctx);
     Tmp<uint32_t> pay_a(ctx), pay_b(ctx), slot(ctx);
     SAMD_TRY(keys_b.get(count));
     SAMD_TRY(pay_a.get(count));
     SAMD_TRY(pay_b.get(count));
+    SAMD_TRY(slot.get(count));
     K *ks = nullptr;
-    uint32_t *perm = nullptr;
-    SAMD_TRY(radix_sort_pairs<K>(ctx, keys.p, keys_b.p, pay_a.p, pay_b.p, count, begin_bit, end_bit, &ks, &perm));
+    const uint32_t *sorted_pay = nullptr;
+    SAMD_TRY((radix_sort_pairs<K, uint32_t>(ctx, keys.p, keys_b.p,
+                                             kIndirect ? (const uint32_t *)nullptr
+                                                       : reinterpret_cast<const uint32_t *>(vals_in),
+                                             pay_a.p, pay_b.p, count, begin_bit, end_bit, &ks, &sorted_pay)));
+    const uint32_t *perm = kIndirect ? sorted_pay : nullptr;
+    const T *vs = kIndirect ? vals_in : reinterpret_cast<const T *>(sorted_pay);
 
     // head flags -> slots; total -> host (the only synchronisation of an assembly)
-    uint32_t *slots = (perm == pay_a.p) ? pay_b.p : pay_a.p;  // the payload buffer not holding perm
+    uint32_t *slots = slot.p;
     SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t) * 2, ctx->stream));
     SAMD_TRY((device_scan<uint32_t, OpAdd, HeadFlagIn<K>, false>(ctx, HeadFlagIn<K>{ks}, count, 0u, OpAdd(), slots,
                                                                   (uint32_t *)ctx->d_small)));
@@ -191,14 +206,14 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     const unsigned grid = (unsigned)cdiv(count, kBlock);
     if (use_col32(ctx, n_minor)) {
       SAMD_TRY(dalloc(ctx, &b->col32, merged));
-      hipLaunchKernelGGL((merge_emit_kernel<K, T, int32_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const K *)ks,
-                         (const uint32_t *)perm, (const uint32_t *)slots, vals_in, count, minor_bits, minor_mask,
-                         b->col32, b->vals, b->row_ptr);
+      hipLaunchKernelGGL((merge_emit_kernel<K, T, int32_t, kIndirect>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                         (const K *)ks, perm, (const uint32_t *)slots, vs, count, minor_bits, minor_mask, b->col32,
+                         b->vals, b->row_ptr);
     } else {
       SAMD_TRY(dalloc(ctx, &b->col64, merged));
-      hipLaunchKernelGGL((merge_emit_kernel<K, T, int64_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const K *)ks,
-                         (const uint32_t *)perm, (const uint32_t *)slots, vals_in, count, minor_bits, minor_mask,
-                         b->col64, b->vals, b->row_ptr);
+      hipLaunchKernelGGL((merge_emit_kernel<K, T, int64_t, kIndirect>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                         (const K *)ks, perm, (const uint32_t *)slots, vs, count, minor_bits, minor_mask, b->col64,
+                         b->vals, b->row_ptr);
     }
     SAMD_LAUNCH_CHECK(ctx);
     if (n_major > 0)
