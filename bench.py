@@ -63,17 +63,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algo", type=int, default=0)
+    # rehearsal switches (defaults are the measured configuration)
+    ap.add_argument("--grid", type=int, default=GRID, help="grid edge per GPU (default 4096 = BASELINE configs[1])")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses N>1 on one GPU")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--exchange", default=None, choices=["halo", "allgather"], help="force the x exchange mode")
+    ap.add_argument("--watchdog", type=int, default=0, help="dump all stacks and exit after this many seconds")
     args = ap.parse_args()
+    if args.watchdog:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if args.same_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -87,7 +101,7 @@ def main():
     M = mk_compressed("f64", ctx)
 
     # ---- build this rank's rows through the product path
-    g = GRID
+    g = args.grid
     n_loc = g * g
     n_glob = n_loc * world
     t_asm0 = time.perf_counter()
@@ -107,7 +121,8 @@ def main():
         nnz0 = r.numel()
         torch.cuda.synchronize()
         t_asm0 = time.perf_counter()
-        D = sd.DistCsr.from_local_coo(M, dist, n_glob, n_glob, rank * n_loc, (rank + 1) * n_loc, r, c, v)
+        D = sd.DistCsr.from_local_coo(M, dist, n_glob, n_glob, rank * n_loc, (rank + 1) * n_loc, r, c, v,
+                                       force_mode=args.exchange)
         ctx.sync()
         asm_s = time.perf_counter() - t_asm0
         del r, c, v
@@ -115,7 +130,7 @@ def main():
         D.x_own.copy_(synth.laplacian_x_device(rank * n_loc, (rank + 1) * n_loc, dev))
         x = D.x_own
     torch.cuda.empty_cache()
-    _, _, nnz = A.stored_dims()
+    nnz = A.stored_dims()[2] if D is None else D.nnz
 
     def step():
         if D is None:
@@ -184,7 +199,7 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and g == GRID:   # the PMC pass was taken on the 4096^2 per-GPU workload
             try:
                 traffic = json.load(open(tpath)).get("spmv_c2_f64_hbm_bytes_per_launch")
             except Exception:

@@ -145,7 +145,16 @@ class ExchangePlan:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
             return x_ext
+        for w in self.exchange_start(x_ext):
+            w.wait()
+        return x_ext
+
+    def exchange_start(self, x_ext):
+        """halo mode: pack and post the point-to-point transfers; returns the work handles."""
+        dist = self.dist
+        own = x_ext[:self.n_own]
         sendbuf = own[self.send_idx]
+        self._sendbuf = sendbuf                         # keep alive until the sends complete
         recv = x_ext[self.n_own:]
         ops, so, ro = [], 0, 0
         for p in range(self.world):
@@ -157,21 +166,27 @@ class ExchangePlan:
                     ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], p))
             so += sc
             ro += rc
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        return x_ext
+        return dist.batch_isend_irecv(ops) if ops else []
 
 
 class DistCsr:
-    """This rank's row block as an ordinary single-GPU CSR record plus the plan
-    that keeps its x up to date."""
+    """This rank's row block as ordinary single-GPU CSR records plus the plan that keeps
+    its x up to date.
 
-    def __init__(self, M, plan, A, n_loc, torch_dtype):
+    halo mode: the block is split by column ownership, A = [A_loc | A_gh].  A_loc (columns
+    this rank owns) is multiplied while the halo entries are still on the wire; A_gh holds
+    only the rows that touch a remote column (compact row numbering) and is added afterwards:
+        y = A_loc x_own ;  y[rows_g] += A_gh x_ghost
+    all-gather / single-rank mode: one record over the whole x."""
+
+    def __init__(self, M, plan, A, n_loc, torch_dtype, A_gh=None, rows_g=None):
         self.M, self.plan, self.A, self.n_loc = M, plan, A, n_loc
+        self.A_gh, self.rows_g = A_gh, rows_g
         self.mode = plan.mode
-        self.x_len = plan.x_len
+        self.x_len = plan.x_len if A_gh is None else plan.n_own
         self.x_ext, self.x_own = plan.new_x(torch_dtype)
+        self.x_ghost = self.x_ext[plan.n_own:] if A_gh is not None else None
+        self.nnz = A.stored_dims()[2] + (A_gh.stored_dims()[2] if A_gh is not None else 0)
 
     @classmethod
     def from_local_coo(cls, M, dist, n_glob, m_glob, row_lo, row_hi, rs, cs, vs, force_mode=None):
@@ -192,18 +207,45 @@ class DistCsr:
         needed = torch.unique(cs)
         plan = ExchangePlan(dist, bounds, needed, dev, force_mode)
         del needed
-        A = M.sr.sparse(row_hi - row_lo, plan.x_len, (rs - row_lo, plan.remap_cols(cs), vs))
-        return cls(M, plan, A, row_hi - row_lo, vs.dtype)
+        n_loc = row_hi - row_lo
+        if plan.mode != "halo":
+            A = M.sr.sparse(n_loc, plan.x_len, (rs - row_lo, plan.remap_cols(cs), vs))
+            return cls(M, plan, A, n_loc, vs.dtype)
+        own = (cs >= plan.lo) & (cs < plan.hi)
+        A = M.sr.sparse(n_loc, plan.n_own, ((rs[own] - row_lo).contiguous(), (cs[own] - plan.lo).contiguous(),
+                                            vs[own].contiguous()))
+        gh = ~own
+        rows_g = torch.unique(rs[gh])                                   # sorted global rows touching a ghost
+        n_gh = max(int(plan.ghost.numel()), 1)
+        A_gh = M.sr.sparse(int(rows_g.numel()), n_gh,
+                           (torch.searchsorted(rows_g, rs[gh]).contiguous(),
+                            torch.searchsorted(plan.ghost, cs[gh]).contiguous(), vs[gh].contiguous()))
+        return cls(M, plan, A, n_loc, vs.dtype, A_gh, (rows_g - row_lo).contiguous())
 
     def exchange(self, x_own=None):
         if x_own is not None and x_own.data_ptr() != self.x_own.data_ptr():
             self.x_own.copy_(x_own)
         return self.plan.exchange(self.x_ext)
 
-    def local_smvm(self, x_ext):
-        return self.M.sr.smvm(self.A, x_ext)
+    def local_smvm(self, x_ext=None):
+        """The dominant kernel alone: this rank's rows against data already in place."""
+        if self.A_gh is not None:
+            return self.M.sr.smvm(self.A, self.x_own)
+        return self.M.sr.smvm(self.A, self.x_ext if x_ext is None else x_ext)
 
     def smvm(self, x_own=None):
         """y[rows of this rank] = A[rows,:] x.  x_own: this rank's slice of x (ideally the
         view DistCsr.x_own itself, then nothing is copied)."""
-        return self.local_smvm(self.exchange(x_own))
+        if self.A_gh is None:
+            return self.local_smvm(self.exchange(x_own))
+        import torch
+        if x_own is not None and x_own.data_ptr() != self.x_own.data_ptr():
+            self.x_own.copy_(x_own)
+        works = self.plan.exchange_start(self.x_ext)       # halo entries go on the wire ...
+        y = self.M.sr.smvm(self.A, self.x_own)             # ... while the owned columns are multiplied
+        for w in works:
+            w.wait()
+        if self.rows_g.numel():
+            yg = self.M.sr.smvm(self.A_gh, self.x_ghost)
+            torch.as_tensor(y, device=self.x_ext.device).index_add_(0, self.rows_g, torch.as_tensor(yg, device=self.x_ext.device))
+        return y

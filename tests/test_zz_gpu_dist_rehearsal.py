@@ -1,0 +1,38 @@
+"""Two ranks on ONE GPU over gloo: the whole N>1 bench path (row shards, ExchangePlan in
+halo and all-gather mode, DistCsr split product, parity gate against the stencil) run end to
+end.  Throughput is meaningless here; bench.py asserts y == stencil bit for bit on every rank
+before it times anything, so exit status 0 + a JSON line is the check."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "512", "--backend", "gloo",
+           "--same-device", "--watchdog", "100"] + extra
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_two_ranks_halo():
+    j = _run([], 29541)
+    assert j["n_gpus"] == 2 and j["config"]["x_exchange"] == "halo"
+    assert j["config"]["nnz_total"] == 5 * 512 * 1024 - 2 * 512 - 2 * 1024      # one 512 x 1024 grid
+
+
+@pytest.mark.gpu
+def test_two_ranks_allgather():
+    j = _run(["--exchange", "allgather"], 29542)
+    assert j["n_gpus"] == 2 and j["config"]["x_exchange"] == "allgather"
