@@ -176,9 +176,18 @@ def main():
         torch.cuda.synchronize()
         kern_ms = ev0.elapsed_time(ev1) / args.steps
         m_loc = D.x_len
+        # the x exchange alone (wall clock: the transfers run on the communicator's own stream)
+        dist.barrier()
+        torch.cuda.synchronize()
+        tx = time.perf_counter()
+        for _ in range(args.steps):
+            D.exchange()
+        torch.cuda.synchronize()
+        ex_ms = (time.perf_counter() - tx) / args.steps * 1e3
     else:
         kern_ms = dev_ms
         m_loc = n_loc
+        ex_ms = 0.0
 
     if dist is not None:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
@@ -211,7 +220,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D 5-point Laplacian CSR f64, %d^2 grid per GPU, SpMV (BASELINE configs[1])" % g,
                        "rows_per_gpu": n_loc, "nnz_per_gpu": nnz, "nnz_total": nnz_glob, "col_idx_bytes": 4,
-                       "x_exchange": "none" if D is None else D.mode,
+                       "x_exchange": "none" if D is None else D.mode, "x_exchange_ms_alone": round(ex_ms, 5),
                        "assembly_s": round(asm_s, 4), "assembly_Mtriples_per_s": round(nnz0 / asm_s / 1e6, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -40,6 +40,67 @@ def partition_rows_equal_nnz(row_off, parts):
     return b
 
 
+def coarse_row_splitters(dist, n_glob, rs, parts, bins_log2=16):
+    """Row-block boundaries with nearly equal triple counts per part, from a coarse global
+    row histogram (<= 2^bins_log2 bins, one all-reduce).  rs: this rank's row ids (any
+    device).  Every rank returns the same parts+1 ascending boundaries."""
+    import torch
+    shift = max(0, int(n_glob - 1).bit_length() - bins_log2) if n_glob > 0 else 0
+    nb = ((n_glob - 1) >> shift) + 1 if n_glob > 0 else 1
+    h = torch.bincount(rs >> shift, minlength=nb).to(torch.int64) if rs.numel() else \
+        torch.zeros(nb, dtype=torch.int64, device=rs.device)
+    if dist is not None and dist.get_world_size() > 1:
+        dist.all_reduce(h)
+    cum = torch.cumsum(h, 0)
+    total = int(cum[-1].item())
+    targets = torch.tensor([(g * total) // parts for g in range(1, parts)], dtype=torch.int64, device=rs.device)
+    cut = torch.searchsorted(cum, targets, right=False) + 1             # bins [0, cut) hold >= target triples
+    b = [0] + [min(int(c) << shift, n_glob) for c in cut.tolist()] + [n_glob]
+    for i in range(1, len(b)):
+        b[i] = max(b[i], b[i - 1])
+    return b
+
+
+def redistribute_coo(dist, bounds, rs, cs, vs):
+    """The one exchange step of distributed assembly: every rank holds an arbitrary chunk of
+    the global triple list; afterwards rank k holds exactly the triples whose row lies in
+    [bounds[k], bounds[k+1]), ordered by (source rank, position in the source chunk) -- i.e.
+    in the order of the concatenated global input, so duplicates are later summed in the same
+    order as on one device.  All pairs swap with grouped point-to-point transfers."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    if world == 1:
+        return rs, cs, vs
+    rank = dist.get_rank()
+    dev = rs.device
+    bt = torch.tensor(list(bounds), dtype=torch.int64, device=dev)
+    dest = torch.searchsorted(bt[1:-1].contiguous(), rs, right=True)    # 0..world-1
+    counts = torch.bincount(dest, minlength=world).to(torch.int64)
+    allc = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allc, counts)
+    send_counts = [int(v) for v in counts.tolist()]
+    recv_counts = [int(allc[p][rank].item()) for p in range(world)]
+    outs = []
+    for arr in (rs, cs, vs):
+        parts = [arr[dest == p].contiguous() for p in range(world)]       # boolean select keeps source order
+        recv = [parts[p] if p == rank else torch.empty(recv_counts[p], dtype=arr.dtype, device=dev)
+                for p in range(world)]
+        ops = []
+        for p in range(world):
+            if p == rank:
+                continue
+            if send_counts[p]:
+                ops.append(dist.P2POp(dist.isend, parts[p], p))
+            if recv_counts[p]:
+                ops.append(dist.P2POp(dist.irecv, recv[p], p))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        outs.append(torch.cat(recv))
+        del parts, recv
+    return tuple(outs)
+
+
 class ExchangePlan:
     """Who sends which x entries to whom.  Pure torch + torch.distributed; works on
     CPU tensors with gloo (tests) and CUDA tensors with nccl/RCCL (product)."""
@@ -189,7 +250,7 @@ class DistCsr:
         self.nnz = A.stored_dims()[2] + (A_gh.stored_dims()[2] if A_gh is not None else 0)
 
     @classmethod
-    def from_local_coo(cls, M, dist, n_glob, m_glob, row_lo, row_hi, rs, cs, vs, force_mode=None):
+    def from_local_coo(cls, M, dist, n_glob, m_glob, row_lo, row_hi, rs, cs, vs, force_mode=None, split=True):
         """rs/cs/vs: this rank's COO triples (torch CUDA tensors, GLOBAL indices, rows in
         [row_lo,row_hi)).  x is partitioned like the rows (square matrices)."""
         import torch
@@ -208,7 +269,7 @@ class DistCsr:
         plan = ExchangePlan(dist, bounds, needed, dev, force_mode)
         del needed
         n_loc = row_hi - row_lo
-        if plan.mode != "halo":
+        if plan.mode != "halo" or not split:
             A = M.sr.sparse(n_loc, plan.x_len, (rs - row_lo, plan.remap_cols(cs), vs))
             return cls(M, plan, A, n_loc, vs.dtype)
         own = (cs >= plan.lo) & (cs < plan.hi)
@@ -221,6 +282,32 @@ class DistCsr:
                            (torch.searchsorted(rows_g, rs[gh]).contiguous(),
                             torch.searchsorted(plan.ghost, cs[gh]).contiguous(), vs[gh].contiguous()))
         return cls(M, plan, A, n_loc, vs.dtype, A_gh, (rows_g - row_lo).contiguous())
+
+    @classmethod
+    def from_coo_chunks(cls, M, dist, n_glob, m_glob, rs, cs, vs, bounds=None, force_mode=None, split=True):
+        """Distributed assembly: every rank passes an arbitrary chunk of the global COO list
+        (GLOBAL indices).  Splitters come from a coarse global row histogram unless given;
+        one all-to-all-v of triples; then the ordinary single-GPU assembly on each rank."""
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
+        if bounds is None:
+            bounds = coarse_row_splitters(dist, n_glob, rs, world)
+        rs, cs, vs = redistribute_coo(dist, bounds, rs, cs, vs)
+        D = cls.from_local_coo(M, dist, n_glob, m_glob, bounds[rank], bounds[rank + 1], rs, cs, vs, force_mode, split)
+        D.bounds = list(bounds)
+        return D
+
+    def nnz_offset(self):
+        """Stored entries on lower ranks (one all-gather of a scalar per rank)."""
+        import torch
+        dist = self.plan.dist
+        if dist is None or self.plan.world == 1:
+            return 0
+        dev = self.x_ext.device
+        mine = torch.tensor([self.nnz], dtype=torch.int64, device=dev)
+        allv = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.plan.world)]
+        dist.all_gather(allv, mine)
+        return sum(int(v.item()) for v in allv[:self.plan.rank])
 
     def exchange(self, x_own=None):
         if x_own is not None and x_own.data_ptr() != self.x_own.data_ptr():
@@ -249,3 +336,25 @@ class DistCsr:
             yg = self.M.sr.smvm(self.A_gh, self.x_ghost)
             torch.as_tensor(y, device=self.x_ext.device).index_add_(0, self.rows_g, torch.as_tensor(yg, device=self.x_ext.device))
         return y
+
+    def smm(self, B_own):
+        """C[rows of this rank][k] = A[rows,:] B for a dense B whose rows are partitioned
+        like x; B_own: this rank's [n_own][k] block (row-major).  Same exchange plan as smvm,
+        moving rows of B instead of scalars."""
+        import torch
+        plan, dev = self.plan, self.x_ext.device
+        k = int(B_own.shape[1])
+        B_ext = torch.empty((plan.x_len, k), dtype=B_own.dtype, device=dev)
+        B_ext[plan.own_offset:plan.own_offset + plan.n_own].copy_(B_own)
+        if self.A_gh is None:
+            plan.exchange(B_ext)
+            return self.M.sr.smm(self.A, B_ext)
+        works = plan.exchange_start(B_ext)
+        C = self.M.sr.smm(self.A, B_ext[:plan.n_own])
+        for w in works:
+            w.wait()
+        if self.rows_g.numel():
+            Cg = self.M.sr.smm(self.A_gh, B_ext[plan.n_own:])
+            torch.as_tensor(C, device=dev).index_add_(0, self.rows_g, torch.as_tensor(Cg, device=dev))
+        return C
+

@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT)
 
 from oracle.oracle import Oracle  # noqa: E402
 from sparse_amd import synth  # noqa: E402
-from sparse_amd.distributed import ExchangePlan, partition_rows_equal_nnz  # noqa: E402
+from sparse_amd.distributed import (ExchangePlan, coarse_row_splitters, partition_rows_equal_nnz,  # noqa: E402
+                                    redistribute_coo)
 
 
 def run_case(name, n, r, c, v, force_mode, bounds=None):
@@ -44,6 +45,38 @@ def run_case(name, n, r, c, v, force_mode, bounds=None):
     plan.exchange(x_ext)
     assert np.array_equal(O.sr_smvm(L, x_ext.numpy()), 2.0 * y_ref[lo:hi]), (name, rank, "refresh")
     return plan.mode, int(plan.x_len)
+
+
+def run_assembly_case(name, n, m, r, c, v, bins_log2=16):
+    """Distributed assembly: each rank starts from an arbitrary (strided) chunk of the global
+    triple list; after the exchange + local assembly the pieces must be, bit for bit, the row
+    blocks of the single-process result (duplicates summed in global input order)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    O = Oracle("f64")
+    G = O.sr_sparse(n, m, r, c, v)
+    # contiguous chunks of unequal length, so that the global input order is rank-major
+    cuts = [0] + [(len(r) * (k + 1) * (k + 2)) // (world * (world + 1)) for k in range(world)]
+    sl = slice(cuts[rank], cuts[rank + 1])
+    tr, tc, tv = (torch.from_numpy(np.ascontiguousarray(a[sl])) for a in (r, c, v))
+    bounds = coarse_row_splitters(dist, n, tr, world, bins_log2)
+    assert bounds[0] == 0 and bounds[-1] == n and all(a <= b for a, b in zip(bounds, bounds[1:])), bounds
+    lr, lc, lv = redistribute_coo(dist, bounds, tr, tc, tv)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    assert lr.numel() == 0 or (int(lr.min()) >= lo and int(lr.max()) < hi)
+    L = O.sr_sparse(hi - lo, m, lr.numpy() - lo, lc.numpy(), lv.numpy())
+    # global row_off = local inclusive scan + entries on lower ranks
+    mine = torch.tensor([L["nnz"]], dtype=torch.int64)
+    allv = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    off = sum(int(x.item()) for x in allv[:rank])
+    assert sum(int(x.item()) for x in allv) == G["nnz"], name
+    assert np.array_equal(L["row_off"] + off, G["row_off"][lo:hi]), (name, rank)
+    assert np.array_equal(L["col_idx"], G["col_idx"][off:off + L["nnz"]]), (name, rank)
+    assert L["vals"].tobytes() == G["vals"][off:off + L["nnz"]].tobytes(), (name, rank)
+    # balance: no part holds more than its share plus one histogram bin's worth of triples
+    tot = torch.tensor([lr.numel()], dtype=torch.int64)
+    dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+    return int(tot.item())
 
 
 def main():
@@ -78,6 +111,19 @@ def main():
     # forcing either path gives the same answer
     run_case("rect-forced-allgather", n, r, c, v, "allgather", even)
     run_case("random-forced-halo", n, rr, cc, vv, "halo", even)
+    # ---- distributed assembly
+    k = 40 * n
+    idx = np.arange(k, dtype=np.uint64)
+    ar = (synth.splitmix64(11, idx) % np.uint64(n)).astype(np.int64)
+    ac = (synth.splitmix64(12, idx) % np.uint64(n // 4)).astype(np.int64)      # many duplicates
+    av = 0.5 + (synth.splitmix64(13, idx) >> np.uint64(11)).astype(np.float64) / 2.0 ** 53
+    worst = run_assembly_case("asm-random-dups", n, n // 4, ar, ac, av)
+    assert worst <= k // world + k // 8, (worst, k)
+    run_assembly_case("asm-coarse-bins", n, n // 4, ar, ac, av, bins_log2=3)
+    skew = (ar.astype(np.float64) ** 3 / float(n) ** 2).astype(np.int64)       # most triples in the first rows
+    run_assembly_case("asm-skewed", n, n // 4, skew, ac, av)
+    run_assembly_case("asm-empty", n, n, ar[:0], ac[:0], av[:0])
+    run_assembly_case("asm-one-row", n, n // 4, np.full(k, n - 1, dtype=np.int64), ac, av)
     dist.barrier()
     if rank == 0:
         print("DIST_OK world=%d" % world)

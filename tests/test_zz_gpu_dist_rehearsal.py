@@ -36,3 +36,12 @@ def test_two_ranks_halo():
 def test_two_ranks_allgather():
     j = _run(["--exchange", "allgather"], 29542)
     assert j["n_gpus"] == 2 and j["config"]["x_exchange"] == "allgather"
+
+
+@pytest.mark.gpu
+def test_two_ranks_assembly_smvm_smm():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0 and "DIST_GPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
