@@ -42,6 +42,30 @@ def library_path():
     return _LIBPATH
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel ships its own libamdhip64.so (soname
+    libamdhip64.so.7) and asks for it by file name; libsparse_amd.so asks for the soname.  If torch comes
+    first the loader hands its copy to us and all is well; if we came first, torch would bring in a second
+    runtime (and a second HSA runtime, which then finds no GPUs, and whose streams mean nothing to ours).
+    So when a torch wheel is installed and not yet loaded, map its runtime first; ours then binds to it."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     global _lib
     if _lib is None:
@@ -49,6 +73,7 @@ def load_library():
             raise LibraryMissing(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % _LIBPATH)
+        _share_hip_runtime_with_torch()
         lib = ctypes.CDLL(_LIBPATH)
         lib.futhark_context_config_new.restype = _VP
         lib.futhark_context_new.restype = _VP

@@ -222,6 +222,37 @@ def test_smvm_laplacian_and_tile_boundaries(ctx):
                           Oi.sr_smvm(Oi.sr_sparse(len(lens), m, rs, cs, vi), xi))
 
 
+@pytest.mark.parametrize("lanes", [0, 1, 4, 64])
+def test_smvm_rows_crossing_tile_ends(ctx, lanes):
+    """Rows that run 1, 63, 64, 65, 200, 1023 ... 3000 entries past the end of the 1024-entry tile they start
+    in (head fragments + fix-up in tile order), at every lanes-per-row setting.  i32: exact."""
+    Oi, Mi = Oracle("i32"), mk(ctx, "i32")
+    lens = []
+    for spill in (1, 2, 63, 64, 65, 66, 200, 1023, 1024, 1025, 3000, 0, 5):
+        # pad to 64 short of a tile boundary, then one row crossing it by `spill`
+        used = sum(lens) % 1024
+        pad = (1024 - 64 - used) % 1024
+        lens += [7] * (pad // 7) + [pad % 7] + [64 + spill, 0, 3]
+    m = 4200
+    cs = np.concatenate([np.sort(np.unique((np.arange(L, dtype=np.int64) * 13 + i) % m)) for i, L in enumerate(lens)])
+    rs = np.concatenate([np.full(L, i, np.int64) for i, L in enumerate(lens)])
+    assert len(rs) == len(cs)
+    vi = synth.uniform_values(5, len(rs), "i32")
+    xi = synth.uniform_values(6, m, "i32")
+    want = Oi.sr_smvm(Oi.sr_sparse(len(lens), m, rs, cs, vi), xi)
+    ctx.set_option("spmv_lanes", lanes)
+    try:
+        A = Mi.sr.sparse(len(lens), m, (rs, cs, vi))
+        assert np.array_equal(Mi.sr.smvm(A, xi).numpy(), want)
+        # the same structure with every row cut to <= 100 entries
+        keep = np.concatenate([np.arange(L) < min(L, 100) for L in np.bincount(rs, minlength=len(lens))])
+        B = Mi.sr.sparse(len(lens), m, (rs[keep], cs[keep], vi[keep]))
+        assert np.array_equal(Mi.sr.smvm(B, xi).numpy(),
+                              Oi.sr_smvm(Oi.sr_sparse(len(lens), m, rs[keep], cs[keep], vi[keep]), xi))
+    finally:
+        ctx.set_option("spmv_lanes", 0)
+
+
 def test_smvm_empty_and_shape_errors(ctx):
     from sparse_amd.compressed import SparseError
     M = mk(ctx, "f64")
