@@ -323,6 +323,167 @@ int futhark_entry_test_smsmm(struct futhark_context *ctx, struct futhark_i32_2d 
                              const struct futhark_i32_1d *in5, const struct futhark_i64_1d *in6,
                              const struct futhark_i64_1d *in7, const struct futhark_i32_1d *in8);
 
+/* ---------------------------------------------------- (4) mono sparse matrices
+ * TT in {f64, f32, i32}  <->  `module mo = mk_mono TT` (S/mono.fut:61): at most one stored
+ * element per row (msr) or per column (msc).  futhark_opaque_msr_TT is mo.sr[n][m]
+ * (record col_idx[n], vals[n], S/mono.fut:95); futhark_opaque_msc_TT is mo.sc[n][m], whose
+ * storage is the msr record of the m x n transpose (S/mono.fut:203).  SURVEY.md 8(f) row 3.
+ */
+#define SPARSE_AMD_DECL_MONO(TT, CT)                                                              \
+  struct futhark_opaque_msr_##TT;                                                                 \
+  struct futhark_opaque_msc_##TT;                                                                 \
+  int futhark_free_opaque_msr_##TT(struct futhark_context *ctx, struct futhark_opaque_msr_##TT *o);\
+  int futhark_free_opaque_msc_##TT(struct futhark_context *ctx, struct futhark_opaque_msc_##TT *o);\
+  /* sparse (S/mono.fut:119-129; sc: :188-189).  Non-zero return for an index out of range  */    \
+  /* and for two elements in one row (one column for msc) -- the reference's two asserts.    */   \
+  int futhark_entry_msr_##TT##_sparse(struct futhark_context *ctx,                                \
+                                      struct futhark_opaque_msr_##TT **out0, const int64_t n,     \
+                                      const int64_t m, const struct futhark_i64_1d *rs,           \
+                                      const struct futhark_i64_1d *cs,                            \
+                                      const struct futhark_##TT##_1d *vs);                        \
+  int futhark_entry_msc_##TT##_sparse(struct futhark_context *ctx,                                \
+                                      struct futhark_opaque_msc_##TT **out0, const int64_t n,     \
+                                      const int64_t m, const struct futhark_i64_1d *rs,           \
+                                      const struct futhark_i64_1d *cs,                            \
+                                      const struct futhark_##TT##_1d *vs);                        \
+  /* zero :97-100 / :170-171, eye :102-105 / :176-177, diag :107-110 / :179-180 */                \
+  int futhark_entry_msr_##TT##_zero(struct futhark_context *ctx,                                  \
+                                    struct futhark_opaque_msr_##TT **out0, const int64_t n,       \
+                                    const int64_t m);                                             \
+  int futhark_entry_msc_##TT##_zero(struct futhark_context *ctx,                                  \
+                                    struct futhark_opaque_msc_##TT **out0, const int64_t n,       \
+                                    const int64_t m);                                             \
+  int futhark_entry_msr_##TT##_eye(struct futhark_context *ctx,                                   \
+                                   struct futhark_opaque_msr_##TT **out0, const int64_t n,        \
+                                   const int64_t m);                                              \
+  int futhark_entry_msc_##TT##_eye(struct futhark_context *ctx,                                   \
+                                   struct futhark_opaque_msc_##TT **out0, const int64_t n,        \
+                                   const int64_t m);                                              \
+  int futhark_entry_msr_##TT##_diag(struct futhark_context *ctx,                                  \
+                                    struct futhark_opaque_msr_##TT **out0,                        \
+                                    const struct futhark_##TT##_1d *v);                           \
+  int futhark_entry_msc_##TT##_diag(struct futhark_context *ctx,                                  \
+                                    struct futhark_opaque_msc_##TT **out0,                        \
+                                    const struct futhark_##TT##_1d *v);                           \
+  /* dense :112-114 / :191-192 */                                                                 \
+  int futhark_entry_msr_##TT##_dense(struct futhark_context *ctx, struct futhark_##TT##_2d **out0,\
+                                     const struct futhark_opaque_msr_##TT *a);                    \
+  int futhark_entry_msc_##TT##_dense(struct futhark_context *ctx, struct futhark_##TT##_2d **out0,\
+                                     const struct futhark_opaque_msc_##TT *a);                    \
+  /* scale :116-117 / :173-174 */                                                                 \
+  int futhark_entry_msr_##TT##_scale(struct futhark_context *ctx,                                 \
+                                     struct futhark_opaque_msr_##TT **out0, const CT v,           \
+                                     const struct futhark_opaque_msr_##TT *a);                    \
+  int futhark_entry_msc_##TT##_scale(struct futhark_context *ctx,                                 \
+                                     struct futhark_opaque_msc_##TT **out0, const CT v,           \
+                                     const struct futhark_opaque_msc_##TT *a);                    \
+  /* nnz :131-133 / :182-183 (stored values that are not zero) */                                 \
+  int futhark_entry_msr_##TT##_nnz(struct futhark_context *ctx, int64_t *out0,                    \
+                                   const struct futhark_opaque_msr_##TT *a);                      \
+  int futhark_entry_msc_##TT##_nnz(struct futhark_context *ctx, int64_t *out0,                    \
+                                   const struct futhark_opaque_msc_##TT *a);                      \
+  /* coo :135-137 / :185-186 (zero values are filtered out, unlike compressed) */                 \
+  int futhark_entry_msr_##TT##_coo(struct futhark_context *ctx, struct futhark_i64_1d **out0,     \
+                                   struct futhark_i64_1d **out1, struct futhark_##TT##_1d **out2, \
+                                   const struct futhark_opaque_msr_##TT *a);                      \
+  int futhark_entry_msc_##TT##_coo(struct futhark_context *ctx, struct futhark_i64_1d **out0,     \
+                                   struct futhark_i64_1d **out1, struct futhark_##TT##_1d **out2, \
+                                   const struct futhark_opaque_msc_##TT *a);                      \
+  /* + and - :139-149 / :194-195: non-zero return when the operands' col_idx differ */            \
+  int futhark_entry_msr_##TT##_add(struct futhark_context *ctx,                                   \
+                                   struct futhark_opaque_msr_##TT **out0,                         \
+                                   const struct futhark_opaque_msr_##TT *a,                       \
+                                   const struct futhark_opaque_msr_##TT *b);                      \
+  int futhark_entry_msr_##TT##_sub(struct futhark_context *ctx,                                   \
+                                   struct futhark_opaque_msr_##TT **out0,                         \
+                                   const struct futhark_opaque_msr_##TT *a,                       \
+                                   const struct futhark_opaque_msr_##TT *b);                      \
+  int futhark_entry_msc_##TT##_add(struct futhark_context *ctx,                                   \
+                                   struct futhark_opaque_msc_##TT **out0,                         \
+                                   const struct futhark_opaque_msc_##TT *a,                       \
+                                   const struct futhark_opaque_msc_##TT *b);                      \
+  int futhark_entry_msc_##TT##_sub(struct futhark_context *ctx,                                   \
+                                   struct futhark_opaque_msc_##TT **out0,                         \
+                                   const struct futhark_opaque_msc_##TT *a,                       \
+                                   const struct futhark_opaque_msc_##TT *b);                      \
+  /* transpose :151-152 / :197-198: no data moves, the handle is re-labelled */                   \
+  int futhark_entry_msr_##TT##_transpose(struct futhark_context *ctx,                             \
+                                         struct futhark_opaque_msc_##TT **out0,                   \
+                                         const struct futhark_opaque_msr_##TT *a);                \
+  int futhark_entry_msc_##TT##_transpose(struct futhark_context *ctx,                             \
+                                         struct futhark_opaque_msr_##TT **out0,                   \
+                                         const struct futhark_opaque_msc_##TT *a);                \
+  /* smvm :154-155 */                                                                             \
+  int futhark_entry_msr_##TT##_smvm(struct futhark_context *ctx, struct futhark_##TT##_1d **out0, \
+                                    const struct futhark_opaque_msr_##TT *a,                      \
+                                    const struct futhark_##TT##_1d *v);                           \
+  /* vsmm :157-159 (msr: scatter-add, summed per column in ascending row order) / :200-201 */     \
+  int futhark_entry_msr_##TT##_vsmm(struct futhark_context *ctx, struct futhark_##TT##_1d **out0, \
+                                    const struct futhark_##TT##_1d *v,                            \
+                                    const struct futhark_opaque_msr_##TT *a);                     \
+  int futhark_entry_msc_##TT##_vsmm(struct futhark_context *ctx, struct futhark_##TT##_1d **out0, \
+                                    const struct futhark_##TT##_1d *a,                            \
+                                    const struct futhark_opaque_msc_##TT *b);                     \
+  /* dmsmm :161-162: dense [n][k] times msr[k][m] -> dense [n][m] */                              \
+  int futhark_entry_msr_##TT##_dmsmm(struct futhark_context *ctx, struct futhark_##TT##_2d **out0,\
+                                     const struct futhark_##TT##_2d *d,                           \
+                                     const struct futhark_opaque_msr_##TT *s);                    \
+  /* extension (no counterpart in the generated API): the record fields col_idx[n], vals[n] */    \
+  /* (for an msc handle: of the transposed record), for bit-for-bit parity tests.           */    \
+  int sparse_amd_msr_##TT##_fields(struct futhark_context *ctx, struct futhark_i64_1d **col_idx,  \
+                                   struct futhark_##TT##_1d **vals,                               \
+                                   const struct futhark_opaque_msr_##TT *a);                      \
+  int sparse_amd_msc_##TT##_fields(struct futhark_context *ctx, struct futhark_i64_1d **col_idx,  \
+                                   struct futhark_##TT##_1d **vals,                               \
+                                   const struct futhark_opaque_msc_##TT *a);
+
+SPARSE_AMD_DECL_MONO(f64, double)
+SPARSE_AMD_DECL_MONO(f32, float)
+SPARSE_AMD_DECL_MONO(i32, int32_t)
+
+/* The reference's own entries for mono (mk_mono i32, S/mono_test.fut:5). */
+#define SPARSE_AMD_COO_ARGS                                                                       \
+  const int64_t in0, const int64_t in1, const struct futhark_i64_1d *in2,                         \
+      const struct futhark_i64_1d *in3, const struct futhark_i32_1d *in4
+/* S/mono_test.fut:30-31 */
+int futhark_entry_test_msr_eye(struct futhark_context *ctx, struct futhark_i32_2d **out0,
+                               const int64_t in0, const int64_t in1);
+/* S/mono_test.fut:42-43 */
+int futhark_entry_test_msr_sparse(struct futhark_context *ctx, struct futhark_i32_2d **out0,
+                                  SPARSE_AMD_COO_ARGS);
+/* S/mono_test.fut:55-57 (in5 is consumed) */
+int futhark_entry_test_msr_smvm(struct futhark_context *ctx, struct futhark_i32_1d **out0,
+                                SPARSE_AMD_COO_ARGS, const struct futhark_i32_1d *in5);
+/* S/mono_test.fut:66-67 */
+int futhark_entry_test_msr_nnz(struct futhark_context *ctx, int64_t *out0, SPARSE_AMD_COO_ARGS);
+/* S/mono_test.fut:74-76 */
+int futhark_entry_test_msr_coo(struct futhark_context *ctx, struct futhark_i64_1d **out0,
+                               struct futhark_i64_1d **out1, struct futhark_i32_1d **out2,
+                               SPARSE_AMD_COO_ARGS);
+/* S/mono_test.fut:87-89: (n, m, v[n], xs, ys, vs) */
+int futhark_entry_test_msr_vsmm(struct futhark_context *ctx, struct futhark_i32_1d **out0,
+                                const int64_t in0, const int64_t in1,
+                                const struct futhark_i32_1d *in2, const struct futhark_i64_1d *in3,
+                                const struct futhark_i64_1d *in4, const struct futhark_i32_1d *in5);
+/* S/mono_test.fut:114-115 */
+int futhark_entry_test_msc_eye(struct futhark_context *ctx, struct futhark_i32_2d **out0,
+                               const int64_t in0, const int64_t in1);
+/* S/mono_test.fut:126-127 */
+int futhark_entry_test_msc_sparse(struct futhark_context *ctx, struct futhark_i32_2d **out0,
+                                  SPARSE_AMD_COO_ARGS);
+/* S/mono_test.fut:136-137 */
+int futhark_entry_test_msc_nnz(struct futhark_context *ctx, int64_t *out0, SPARSE_AMD_COO_ARGS);
+/* S/mono_test.fut:144-146 */
+int futhark_entry_test_msc_coo(struct futhark_context *ctx, struct futhark_i64_1d **out0,
+                               struct futhark_i64_1d **out1, struct futhark_i32_1d **out2,
+                               SPARSE_AMD_COO_ARGS);
+/* S/mono_test.fut:153-155 */
+int futhark_entry_test_msr_transpose(struct futhark_context *ctx, struct futhark_i32_2d **out0,
+                                     SPARSE_AMD_COO_ARGS);
+/* S/mono_test.fut:162-164 */
+int futhark_entry_test_msc_transpose(struct futhark_context *ctx, struct futhark_i32_2d **out0,
+                                     SPARSE_AMD_COO_ARGS);
+
 /* ------------------------------------------------- (3) context extensions
  * No counterpart in the generated API. */
 /* Run all subsequent work on the caller's HIP stream (hipStream_t); the context

@@ -8,6 +8,9 @@
  * What it restates: /root/reference/lib/github.com/diku-dk/sparse/compressed.fut
  * (module mk_compressed, lines 61-332) for element types f64, f32 and i32.
  * Each function in compressed_oracle.inc cites the lines it follows.
+ * mono_oracle.inc restates mono.fut (module mk_mono, lines 61-209) the same way;
+ * it is pinned by the 30 known-answer vectors of mono_test.fut
+ * (tests/golden/mono_kat.json).
  *
  * Why a restatement: the reference is Futhark source; no `futhark` compiler is
  * present in this image and the arithmetic-bearing helpers are un-vendored
@@ -38,18 +41,21 @@
 #define T double
 #define SFX f64
 #include "compressed_oracle.inc"
+#include "mono_oracle.inc"
 #undef T
 #undef SFX
 
 #define T float
 #define SFX f32
 #include "compressed_oracle.inc"
+#include "mono_oracle.inc"
 #undef T
 #undef SFX
 
 #define T int32_t
 #define SFX i32
 #include "compressed_oracle.inc"
+#include "mono_oracle.inc"
 #undef T
 #undef SFX
 

@@ -228,3 +228,108 @@ class Oracle:
                                      _p(ro), _p(ci), _p(va), ctypes.c_int64(cap), ctypes.byref(nnz))
         assert rc == 0, rc
         return self._mat(n, k, nnz.value, ro, ci, va)
+
+    # ===================================================================== mono
+    # Records are dicts {"n","m","col_idx"[n],"vals"[n]} of the STORED sr.mat (mono.fut:95);
+    # an sc matrix of shape n x m is the stored record with n and m swapped (mono.fut:203).
+    @staticmethod
+    def _mono(n, m, ci, va):
+        return {"n": int(n), "m": int(m), "col_idx": ci, "vals": va}
+
+    def msr_sparse(self, n, m, rs, cs, vs):
+        rs, cs, vs = _i64(rs), _i64(cs), self._vals(vs)
+        ci = np.zeros(max(n, 0), np.int64)
+        va = np.zeros(max(n, 0), self.np)
+        rc = self._f("oracle_msr_sparse")(ctypes.c_int64(n), ctypes.c_int64(m), ctypes.c_int64(len(rs)),
+                                          _p(rs), _p(cs), _p(vs), _p(ci), _p(va))
+        if rc == 1:
+            raise ValueError("oracle: index out of bounds (mono.fut:120-121 assert)")
+        if rc == 2:
+            raise ValueError("oracle: two elements in one row (mono.fut:122-126 assert)")
+        return self._mono(n, m, ci, va)
+
+    def msc_sparse(self, n, m, rs, cs, vs):
+        """mono.fut:188-189: map swap coo |> sr.sparse m n."""
+        return self.msr_sparse(m, n, cs, rs, vs)
+
+    def msr_zero(self, n, m):       # mono.fut:97-100
+        return self._mono(n, m, np.zeros(n, np.int64), np.zeros(n, self.np))
+
+    def msr_eye(self, n, m):        # mono.fut:102-105: col_idx = iota n whatever m is
+        return self._mono(n, m, np.arange(n, dtype=np.int64), np.ones(n, self.np))
+
+    def msr_diag(self, v):          # mono.fut:107-110
+        v = self._vals(v)
+        return self._mono(len(v), len(v), np.arange(len(v), dtype=np.int64), v.copy())
+
+    def msr_scale(self, v, A):      # mono.fut:116-117 (T.* v)
+        return self._mono(A["n"], A["m"], A["col_idx"].copy(), (self.np(v) * A["vals"]).astype(self.np))
+
+    def msr_dense(self, A):
+        out = np.zeros((A["n"], A["m"]), self.np)
+        if A["n"] * A["m"] > 0:
+            self._f("oracle_msr_dense", None)(ctypes.c_int64(A["n"]), ctypes.c_int64(A["m"]), _p(A["col_idx"]),
+                                             _p(A["vals"]), _p(out))
+        return out
+
+    def msc_dense(self, A):         # mono.fut:191-192
+        return np.ascontiguousarray(self.msr_dense(A).T)
+
+    def msr_nnz(self, A):
+        return int(self._f("oracle_msr_nnz", ctypes.c_int64)(ctypes.c_int64(A["n"]), _p(A["vals"])))
+
+    def msr_coo(self, A):
+        n = A["n"]
+        r, c, v = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), self.np)
+        k = int(self._f("oracle_msr_coo", ctypes.c_int64)(ctypes.c_int64(n), _p(A["col_idx"]), _p(A["vals"]),
+                                                         _p(r), _p(c), _p(v)))
+        return r[:k], c[:k], v[:k]
+
+    def msc_coo(self, A):           # mono.fut:185-186
+        r, c, v = self.msr_coo(A)
+        return c, r, v
+
+    def _msr_addsub(self, sub, A, B):
+        assert A["n"] == B["n"] and A["m"] == B["m"]
+        ci, va = np.zeros(A["n"], np.int64), np.zeros(A["n"], self.np)
+        rc = self._f("oracle_msr_addsub")(ctypes.c_int(sub), ctypes.c_int64(A["n"]), _p(A["col_idx"]), _p(A["vals"]),
+                                          _p(B["col_idx"]), _p(B["vals"]), _p(ci), _p(va))
+        if rc:
+            raise ValueError("oracle: column indices differ (mono.fut:141/:147 assert)")
+        return self._mono(A["n"], A["m"], ci, va)
+
+    def msr_add(self, A, B):
+        return self._msr_addsub(0, A, B)
+
+    def msr_sub(self, A, B):
+        return self._msr_addsub(1, A, B)
+
+    def msr_smvm(self, A, v):
+        v = self._vals(v)
+        assert len(v) == A["m"]
+        y = np.zeros(A["n"], self.np)
+        rc = self._f("oracle_msr_smvm")(ctypes.c_int64(A["n"]), ctypes.c_int64(A["m"]), _p(A["col_idx"]),
+                                        _p(A["vals"]), _p(v), _p(y))
+        if rc:
+            raise ValueError("oracle: index out of bounds in smvm")
+        return y
+
+    def msr_vsmm(self, v, A):
+        v = self._vals(v)
+        assert len(v) == A["n"]
+        out = np.zeros(A["m"], self.np)
+        self._f("oracle_msr_vsmm", None)(ctypes.c_int64(A["n"]), ctypes.c_int64(A["m"]), _p(v), _p(A["col_idx"]),
+                                        _p(A["vals"]), _p(out))
+        return out
+
+    def msc_vsmm(self, a, B):       # mono.fut:200-201: sr.smvm (transpose b) a
+        return self.msr_smvm(B, a)
+
+    def msr_dmsmm(self, D, S):
+        D = np.ascontiguousarray(np.asarray(D, dtype=self.np))
+        assert D.shape[1] == S["n"]
+        out = np.zeros((D.shape[0], S["m"]), self.np)
+        self._f("oracle_msr_dmsmm", None)(ctypes.c_int64(D.shape[0]), ctypes.c_int64(S["n"]), ctypes.c_int64(S["m"]),
+                                         _p(D), _p(S["col_idx"]), _p(S["vals"]), _p(out))
+        return out
+

@@ -9,6 +9,7 @@
 #include "spmv.hpp"
 #include "spmm.hpp"
 #include "convert.hpp"
+#include "mono.hpp"
 
 using namespace samd;
 
@@ -27,6 +28,12 @@ struct futhark_opaque_csr_f32 { CsrBody<float> *b; };
 struct futhark_opaque_csc_f32 { CsrBody<float> *b; };
 struct futhark_opaque_csr_i32 { CsrBody<int32_t> *b; };
 struct futhark_opaque_csc_i32 { CsrBody<int32_t> *b; };
+struct futhark_opaque_msr_f64 { MonoBody<double> *b; };
+struct futhark_opaque_msc_f64 { MonoBody<double> *b; };
+struct futhark_opaque_msr_f32 { MonoBody<float> *b; };
+struct futhark_opaque_msc_f32 { MonoBody<float> *b; };
+struct futhark_opaque_msr_i32 { MonoBody<int32_t> *b; };
+struct futhark_opaque_msc_i32 { MonoBody<int32_t> *b; };
 
 namespace {
 
@@ -277,6 +284,134 @@ int e_from_fields(futhark_context *ctx, H **out, int64_t n, int64_t m, const fut
   CsrBody<T> *b = nullptr;
   SAMD_TRY(from_fields<T>(ctx, n, m, ro->data, ci->data, va->data, ci->shape[0], &b));
   return wrap_body(ctx, out, b);
+}
+
+// ---- mono (S/mono.fut): typed entry bodies
+template <class H, class T>
+int m_wrap(H **out, MonoBody<T> *b) {
+  H *h = new H();
+  h->b = b;
+  *out = h;
+  return 0;
+}
+
+template <class H>
+int m_free(futhark_context *ctx, H *h) {
+  if (!h) return 0;
+  mono_release(ctx, h->b);
+  delete h;
+  return 0;
+}
+
+template <class T, class H, class VA>
+int m_sparse(futhark_context *ctx, H **out, int64_t n, int64_t m, const futhark_i64_1d *rows,
+             const futhark_i64_1d *cols, const VA *vs) {
+  if (rows->shape[0] != cols->shape[0] || rows->shape[0] != vs->shape[0])
+    return set_error(ctx, "sparse: coordinate arrays differ in length");
+  MonoBody<T> *b = nullptr;
+  SAMD_TRY(mono_sparse<T>(ctx, n, m, rows->data, cols->data, vs->data, rows->shape[0], &b));
+  return m_wrap(out, b);
+}
+
+template <class T, class H>
+int m_make(futhark_context *ctx, H **out, int64_t n, int64_t m, int mode, const T *diag) {
+  MonoBody<T> *b = nullptr;
+  SAMD_TRY(mono_make<T>(ctx, n, m, mode, diag, &b));
+  return m_wrap(out, b);
+}
+
+template <class T, class H, class A2>
+int m_dense(futhark_context *ctx, A2 **out, const H *a, bool is_msc) {
+  const int64_t shape[2] = {is_msc ? a->b->m : a->b->n, is_msc ? a->b->n : a->b->m};
+  A2 *o = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &o, shape, 2));
+  if (mono_dense<T>(ctx, a->b, is_msc, o->data) != 0) { arr_free(ctx, o); return 1; }
+  *out = o;
+  return 0;
+}
+
+template <class T, class H>
+int m_map(futhark_context *ctx, H **out, const H *a, const H *b2, T s, int op) {
+  MonoBody<T> *b = nullptr;
+  SAMD_TRY(mono_map<T>(ctx, a->b, b2 ? b2->b : nullptr, s, op, &b));
+  return m_wrap(out, b);
+}
+
+template <class T, class H, class VA>
+int m_coo(futhark_context *ctx, futhark_i64_1d **o0, futhark_i64_1d **o1, VA **o2, const H *a, bool is_msc) {
+  Tmp<uint32_t> slots(ctx);
+  int64_t count = 0;
+  SAMD_TRY(mono_coo_count<T>(ctx, a->b, slots, &count));
+  const int64_t shape[1] = {count};
+  futhark_i64_1d *r = nullptr, *c = nullptr;
+  VA *v = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &r, shape, 1));
+  if (arr_alloc(ctx, &c, shape, 1) != 0) { arr_free(ctx, r); return 1; }
+  if (arr_alloc(ctx, &v, shape, 1) != 0) { arr_free(ctx, r); arr_free(ctx, c); return 1; }
+  if (mono_coo_emit<T>(ctx, a->b, slots.p, is_msc, r->data, c->data, v->data) != 0) {
+    arr_free(ctx, r); arr_free(ctx, c); arr_free(ctx, v);
+    return 1;
+  }
+  *o0 = r; *o1 = c; *o2 = v;
+  return 0;
+}
+
+template <class HO, class HI>
+int m_relabel(HO **out, const HI *a) {
+  a->b->refs++;
+  return m_wrap(out, a->b);
+}
+
+template <class T, class H, class VA>
+int m_smvm(futhark_context *ctx, VA **out, const H *a, const VA *x) {
+  if (x->shape[0] != a->b->m) return set_error(ctx, "smvm: vector length %lld does not match matrix (%lld)",
+                                               (long long)x->shape[0], (long long)a->b->m);
+  const int64_t shape[1] = {a->b->n};
+  VA *y = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &y, shape, 1));
+  if (mono_smvm<T>(ctx, a->b, x->data, y->data) != 0) { arr_free(ctx, y); return 1; }
+  *out = y;
+  return 0;
+}
+
+template <class T, class H, class VA>
+int m_vsmm(futhark_context *ctx, VA **out, const VA *v, const H *a) {
+  if (v->shape[0] != a->b->n) return set_error(ctx, "vsmm: vector length %lld does not match matrix (%lld)",
+                                               (long long)v->shape[0], (long long)a->b->n);
+  const int64_t room[1] = {a->b->m + 1};  // + the bin of out-of-range columns, not part of the result
+  VA *y = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &y, room, 1));
+  if (mono_vsmm<T>(ctx, a->b, v->data, y->data) != 0) { arr_free(ctx, y); return 1; }
+  y->shape[0] = a->b->m;
+  *out = y;
+  return 0;
+}
+
+template <class T, class H, class A2>
+int m_dmsmm(futhark_context *ctx, A2 **out, const A2 *d, const H *s) {
+  if (d->shape[1] != s->b->n) return set_error(ctx, "dmsmm: dense operand has %lld columns, matrix has %lld rows",
+                                               (long long)d->shape[1], (long long)s->b->n);
+  const int64_t shape[2] = {d->shape[0], s->b->m};
+  A2 *o = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &o, shape, 2));
+  if (mono_dmsmm<T>(ctx, d->data, d->shape[0], s->b, o->data) != 0) { arr_free(ctx, o); return 1; }
+  *out = o;
+  return 0;
+}
+
+template <class T, class H, class VA>
+int m_fields(futhark_context *ctx, futhark_i64_1d **ci, VA **va, const H *a) {
+  const int64_t sn[1] = {a->b->n};
+  futhark_i64_1d *c = nullptr;
+  VA *v = nullptr;
+  SAMD_TRY(arr_alloc(ctx, &c, sn, 1));
+  if (arr_alloc(ctx, &v, sn, 1) != 0) { arr_free(ctx, c); return 1; }
+  if (a->b->n > 0) {
+    SAMD_HIP(ctx, hipMemcpyAsync(c->data, a->b->col, sizeof(int64_t) * (size_t)a->b->n, hipMemcpyDeviceToDevice, ctx->stream));
+    SAMD_HIP(ctx, hipMemcpyAsync(v->data, a->b->vals, sizeof(T) * (size_t)a->b->n, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  *ci = c; *va = v;
+  return 0;
 }
 
 }  // namespace
@@ -776,6 +911,258 @@ int futhark_entry_test_smsmm(CTX, mat_i32 **out0, const int64_t in0, const int64
   free_handle(ctx, C);
   free_handle(ctx, B);
   free_handle(ctx, A);
+  return rc;
+}
+
+// --------------------------------------------------------- mono (S/mono.fut)
+#define MSR(TT) struct futhark_opaque_msr_##TT
+#define MSC(TT) struct futhark_opaque_msc_##TT
+
+#define SAMD_MONO(TT, CT)                                                                                      \
+  int futhark_free_opaque_msr_##TT(CTX, MSR(TT) * o) { ENTER(ctx); return m_free(ctx, o); }                   \
+  int futhark_free_opaque_msc_##TT(CTX, MSC(TT) * o) { ENTER(ctx); return m_free(ctx, o); }                   \
+  int futhark_entry_msr_##TT##_sparse(CTX, MSR(TT) * *out0, const int64_t n, const int64_t m, I64A *rs,        \
+                                      I64A *cs, const A1(TT) * vs) {                                           \
+    ENTER(ctx);                                                                                                \
+    return m_sparse<CT>(ctx, out0, n, m, rs, cs, vs);                                                          \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_sparse(CTX, MSC(TT) * *out0, const int64_t n, const int64_t m, I64A *rs,        \
+                                      I64A *cs, const A1(TT) * vs) {                                           \
+    ENTER(ctx); /* map swap coo |> sr.sparse m n */                                                            \
+    return m_sparse<CT>(ctx, out0, m, n, cs, rs, vs);                                                          \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_zero(CTX, MSR(TT) * *out0, const int64_t n, const int64_t m) {                  \
+    ENTER(ctx);                                                                                                \
+    return m_make<CT>(ctx, out0, n, m, 0, nullptr);                                                            \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_zero(CTX, MSC(TT) * *out0, const int64_t n, const int64_t m) {                  \
+    ENTER(ctx);                                                                                                \
+    return m_make<CT>(ctx, out0, m, n, 0, nullptr);                                                            \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_eye(CTX, MSR(TT) * *out0, const int64_t n, const int64_t m) {                   \
+    ENTER(ctx);                                                                                                \
+    return m_make<CT>(ctx, out0, n, m, 1, nullptr);                                                            \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_eye(CTX, MSC(TT) * *out0, const int64_t n, const int64_t m) {                   \
+    ENTER(ctx);                                                                                                \
+    return m_make<CT>(ctx, out0, m, n, 1, nullptr);                                                            \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_diag(CTX, MSR(TT) * *out0, const A1(TT) * v) {                                  \
+    ENTER(ctx);                                                                                                \
+    return m_make<CT>(ctx, out0, v->shape[0], v->shape[0], 2, v->data);                                        \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_diag(CTX, MSC(TT) * *out0, const A1(TT) * v) {                                  \
+    ENTER(ctx);                                                                                                \
+    return m_make<CT>(ctx, out0, v->shape[0], v->shape[0], 2, v->data);                                        \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_dense(CTX, A2(TT) * *out0, const MSR(TT) * a) {                                 \
+    ENTER(ctx);                                                                                                \
+    return m_dense<CT>(ctx, out0, a, false);                                                                   \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_dense(CTX, A2(TT) * *out0, const MSC(TT) * a) {                                 \
+    ENTER(ctx);                                                                                                \
+    return m_dense<CT>(ctx, out0, a, true);                                                                    \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_scale(CTX, MSR(TT) * *out0, const CT v, const MSR(TT) * a) {                    \
+    ENTER(ctx);                                                                                                \
+    return m_map<CT>(ctx, out0, a, (const MSR(TT) *)nullptr, v, 0);                                            \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_scale(CTX, MSC(TT) * *out0, const CT v, const MSC(TT) * a) {                    \
+    ENTER(ctx);                                                                                                \
+    return m_map<CT>(ctx, out0, a, (const MSC(TT) *)nullptr, v, 0);                                            \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_nnz(CTX, int64_t *out0, const MSR(TT) * a) {                                    \
+    ENTER(ctx);                                                                                                \
+    return mono_nnz<CT>(ctx, a->b, out0);                                                                      \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_nnz(CTX, int64_t *out0, const MSC(TT) * a) {                                    \
+    ENTER(ctx);                                                                                                \
+    return mono_nnz<CT>(ctx, a->b, out0);                                                                      \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_coo(CTX, struct futhark_i64_1d **out0, struct futhark_i64_1d **out1,            \
+                                   A1(TT) * *out2, const MSR(TT) * a) {                                        \
+    ENTER(ctx);                                                                                                \
+    return m_coo<CT>(ctx, out0, out1, out2, a, false);                                                         \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_coo(CTX, struct futhark_i64_1d **out0, struct futhark_i64_1d **out1,            \
+                                   A1(TT) * *out2, const MSC(TT) * a) {                                        \
+    ENTER(ctx);                                                                                                \
+    return m_coo<CT>(ctx, out0, out1, out2, a, true);                                                          \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_add(CTX, MSR(TT) * *out0, const MSR(TT) * a, const MSR(TT) * b) {               \
+    ENTER(ctx);                                                                                                \
+    return m_map<CT>(ctx, out0, a, b, (CT)0, 1);                                                               \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_sub(CTX, MSR(TT) * *out0, const MSR(TT) * a, const MSR(TT) * b) {               \
+    ENTER(ctx);                                                                                                \
+    return m_map<CT>(ctx, out0, a, b, (CT)0, 2);                                                               \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_add(CTX, MSC(TT) * *out0, const MSC(TT) * a, const MSC(TT) * b) {               \
+    ENTER(ctx);                                                                                                \
+    return m_map<CT>(ctx, out0, a, b, (CT)0, 1);                                                               \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_sub(CTX, MSC(TT) * *out0, const MSC(TT) * a, const MSC(TT) * b) {               \
+    ENTER(ctx);                                                                                                \
+    return m_map<CT>(ctx, out0, a, b, (CT)0, 2);                                                               \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_transpose(CTX, MSC(TT) * *out0, const MSR(TT) * a) {                            \
+    ENTER(ctx);                                                                                                \
+    return m_relabel(out0, a);                                                                                 \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_transpose(CTX, MSR(TT) * *out0, const MSC(TT) * a) {                            \
+    ENTER(ctx);                                                                                                \
+    return m_relabel(out0, a);                                                                                 \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_smvm(CTX, A1(TT) * *out0, const MSR(TT) * a, const A1(TT) * v) {                \
+    ENTER(ctx);                                                                                                \
+    return m_smvm<CT>(ctx, out0, a, v);                                                                        \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_vsmm(CTX, A1(TT) * *out0, const A1(TT) * v, const MSR(TT) * a) {                \
+    ENTER(ctx);                                                                                                \
+    return m_vsmm<CT>(ctx, out0, v, a);                                                                        \
+  }                                                                                                            \
+  int futhark_entry_msc_##TT##_vsmm(CTX, A1(TT) * *out0, const A1(TT) * a, const MSC(TT) * b) {                \
+    ENTER(ctx); /* sr.smvm (transpose b) a */                                                                  \
+    return m_smvm<CT>(ctx, out0, b, a);                                                                        \
+  }                                                                                                            \
+  int futhark_entry_msr_##TT##_dmsmm(CTX, A2(TT) * *out0, const A2(TT) * d, const MSR(TT) * s) {               \
+    ENTER(ctx);                                                                                                \
+    return m_dmsmm<CT>(ctx, out0, d, s);                                                                       \
+  }                                                                                                            \
+  int sparse_amd_msr_##TT##_fields(CTX, struct futhark_i64_1d **col_idx, A1(TT) * *vals, const MSR(TT) * a) {  \
+    ENTER(ctx);                                                                                                \
+    return m_fields<CT>(ctx, col_idx, vals, a);                                                                \
+  }                                                                                                            \
+  int sparse_amd_msc_##TT##_fields(CTX, struct futhark_i64_1d **col_idx, A1(TT) * *vals, const MSC(TT) * a) {  \
+    ENTER(ctx);                                                                                                \
+    return m_fields<CT>(ctx, col_idx, vals, a);                                                                \
+  }
+
+SAMD_MONO(f64, double)
+SAMD_MONO(f32, float)
+SAMD_MONO(i32, int32_t)
+
+// The reference's own mono entries (module i32, mono_test.fut): each body is the composition
+// written at the cited lines.
+typedef struct futhark_opaque_msr_i32 msr_i32;
+typedef struct futhark_opaque_msc_i32 msc_i32;
+#define COO_ARGS const int64_t in0, const int64_t in1, carr_i64 *in2, carr_i64 *in3, const arr_i32 *in4
+
+// mono_test.fut:30-31  msr.eye n m |> msr.dense
+int futhark_entry_test_msr_eye(CTX, mat_i32 **out0, const int64_t in0, const int64_t in1) {
+  ENTER(ctx);
+  msr_i32 *a = nullptr;
+  SAMD_TRY(m_make<int32_t>(ctx, &a, in0, in1, 1, nullptr));
+  int rc = m_dense<int32_t>(ctx, out0, a, false);
+  m_free(ctx, a);
+  return rc;
+}
+// :42-43
+int futhark_entry_test_msr_sparse(CTX, mat_i32 **out0, COO_ARGS) {
+  ENTER(ctx);
+  msr_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  int rc = m_dense<int32_t>(ctx, out0, a, false);
+  m_free(ctx, a);
+  return rc;
+}
+// :55-57
+int futhark_entry_test_msr_smvm(CTX, arr_i32 **out0, COO_ARGS, const arr_i32 *in5) {
+  ENTER(ctx);
+  msr_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  int rc = m_smvm<int32_t>(ctx, out0, a, in5);
+  m_free(ctx, a);
+  return rc;
+}
+// :66-67
+int futhark_entry_test_msr_nnz(CTX, int64_t *out0, COO_ARGS) {
+  ENTER(ctx);
+  msr_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  int rc = mono_nnz<int32_t>(ctx, a->b, out0);
+  m_free(ctx, a);
+  return rc;
+}
+// :74-76
+int futhark_entry_test_msr_coo(CTX, struct futhark_i64_1d **out0, struct futhark_i64_1d **out1, arr_i32 **out2,
+                               COO_ARGS) {
+  ENTER(ctx);
+  msr_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  int rc = m_coo<int32_t>(ctx, out0, out1, out2, a, false);
+  m_free(ctx, a);
+  return rc;
+}
+// :87-89  (n, m, v, xs, ys, vs)
+int futhark_entry_test_msr_vsmm(CTX, arr_i32 **out0, const int64_t in0, const int64_t in1, const arr_i32 *in2,
+                                carr_i64 *in3, carr_i64 *in4, const arr_i32 *in5) {
+  ENTER(ctx);
+  msr_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in0, in1, in3, in4, in5));
+  int rc = m_vsmm<int32_t>(ctx, out0, in2, a);
+  m_free(ctx, a);
+  return rc;
+}
+// :114-115  msc.eye n m |> msc.dense
+int futhark_entry_test_msc_eye(CTX, mat_i32 **out0, const int64_t in0, const int64_t in1) {
+  ENTER(ctx);
+  msc_i32 *a = nullptr;
+  SAMD_TRY(m_make<int32_t>(ctx, &a, in1, in0, 1, nullptr));
+  int rc = m_dense<int32_t>(ctx, out0, a, true);
+  m_free(ctx, a);
+  return rc;
+}
+// :126-127
+int futhark_entry_test_msc_sparse(CTX, mat_i32 **out0, COO_ARGS) {
+  ENTER(ctx);
+  msc_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in1, in0, in3, in2, in4));
+  int rc = m_dense<int32_t>(ctx, out0, a, true);
+  m_free(ctx, a);
+  return rc;
+}
+// :136-137
+int futhark_entry_test_msc_nnz(CTX, int64_t *out0, COO_ARGS) {
+  ENTER(ctx);
+  msc_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in1, in0, in3, in2, in4));
+  int rc = mono_nnz<int32_t>(ctx, a->b, out0);
+  m_free(ctx, a);
+  return rc;
+}
+// :144-146
+int futhark_entry_test_msc_coo(CTX, struct futhark_i64_1d **out0, struct futhark_i64_1d **out1, arr_i32 **out2,
+                               COO_ARGS) {
+  ENTER(ctx);
+  msc_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in1, in0, in3, in2, in4));
+  int rc = m_coo<int32_t>(ctx, out0, out1, out2, a, true);
+  m_free(ctx, a);
+  return rc;
+}
+// :153-155  msr.sparse n m ... |> msr.transpose |> msc.dense
+int futhark_entry_test_msr_transpose(CTX, mat_i32 **out0, COO_ARGS) {
+  ENTER(ctx);
+  msr_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in0, in1, in2, in3, in4));
+  msc_i32 *t = nullptr;
+  m_relabel(&t, a);
+  int rc = m_dense<int32_t>(ctx, out0, t, true);
+  m_free(ctx, t);
+  m_free(ctx, a);
+  return rc;
+}
+// :162-164  msc.sparse n m ... |> msc.transpose |> msr.dense
+int futhark_entry_test_msc_transpose(CTX, mat_i32 **out0, COO_ARGS) {
+  ENTER(ctx);
+  msc_i32 *a = nullptr;
+  SAMD_TRY(m_sparse<int32_t>(ctx, &a, in1, in0, in3, in2, in4));
+  msr_i32 *t = nullptr;
+  m_relabel(&t, a);
+  int rc = m_dense<int32_t>(ctx, out0, t, false);
+  m_free(ctx, t);
+  m_free(ctx, a);
   return rc;
 }
 

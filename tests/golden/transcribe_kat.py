@@ -11,6 +11,9 @@ Run in the build container (the reference is not present on the GPU box):
     python tests/golden/transcribe_kat.py \
         /root/reference/lib/github.com/diku-dk/sparse/compressed_test.fut \
         tests/golden/compressed_kat.json
+    python tests/golden/transcribe_kat.py \
+        /root/reference/lib/github.com/diku-dk/sparse/mono_test.fut \
+        tests/golden/mono_kat.json
 """
 import json
 import re
@@ -107,7 +110,7 @@ def main(src, dst):
         i += 1
     doc = {"source": "diku-dk/sparse lib/github.com/diku-dk/sparse/" + src.split("/")[-1],
            "note": "literals of the reference's futhark-test blocks; element type of the module under "
-                   "test is i32 (compressed_test.fut:5)",
+                   "test is i32 (line 5 of the test file)",
            "cases": cases}
     json.dump(doc, open(dst, "w"), indent=1)
     print("wrote %d cases to %s" % (len(cases), dst))

@@ -70,6 +70,54 @@ class OracleCompressed:
         return self.O.smsmm(A, B)
 
 
+class _OMSR:
+    """mono sr over the oracle (mono.fut:93-163)."""
+    def __init__(self, O):
+        self.O = O
+
+    def zero(self, n, m): return self.O.msr_zero(n, m)
+    def eye(self, n, m): return self.O.msr_eye(n, m)
+    def diag(self, v): return self.O.msr_diag(v)
+    def dense(self, A): return self.O.msr_dense(A)
+    def scale(self, v, A): return self.O.msr_scale(v, A)
+    def sparse(self, n, m, coo): return self.O.msr_sparse(n, m, *coo)
+    def nnz(self, A): return self.O.msr_nnz(A)
+    def coo(self, A): return self.O.msr_coo(A)
+    def add(self, A, B): return self.O.msr_add(A, B)
+    def sub(self, A, B): return self.O.msr_sub(A, B)
+    def transpose(self, A): return A            # mono.fut:151-152
+    def smvm(self, A, v): return self.O.msr_smvm(A, v)
+    def vsmm(self, v, A): return self.O.msr_vsmm(v, A)
+    def dmsmm(self, D, S): return self.O.msr_dmsmm(D, S)
+
+
+class _OMSC:
+    """sc.mat[n][m] = sr.mat[m][n] (mono.fut:203): every member delegates (:166-201)."""
+    def __init__(self, O):
+        self.O = O
+
+    def zero(self, n, m): return self.O.msr_zero(m, n)
+    def eye(self, n, m): return self.O.msr_eye(m, n)
+    def diag(self, v): return self.O.msr_diag(v)
+    def dense(self, A): return self.O.msc_dense(A)
+    def scale(self, v, A): return self.O.msr_scale(v, A)
+    def sparse(self, n, m, coo): return self.O.msc_sparse(n, m, *coo)
+    def nnz(self, A): return self.O.msr_nnz(A)
+    def coo(self, A): return self.O.msc_coo(A)
+    def add(self, A, B): return self.O.msr_add(A, B)
+    def sub(self, A, B): return self.O.msr_sub(A, B)
+    def transpose(self, A): return A            # mono.fut:197-198
+    def vsmm(self, a, B): return self.O.msc_vsmm(a, B)
+
+
+class OracleMono:
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.O = Oracle(dtype)
+        self.sr = _OMSR(self.O)
+        self.sc = _OMSC(self.O)
+
+
 # --- the reference's test entries, restated over the module surface ---------
 def _coo(xs, ys, vs):
     return (xs, ys, vs)
@@ -107,6 +155,36 @@ ENTRIES = {
 }
 
 
+MONO_ENTRIES = {
+    # mono_test.fut:30-31
+    "test_msr_eye": lambda c, n, m: [c.sr.dense(c.sr.eye(n, m))],
+    # :42-43
+    "test_msr_sparse": lambda c, n, m, xs, ys, vs: [c.sr.dense(c.sr.sparse(n, m, _coo(xs, ys, vs)))],
+    # :55-57
+    "test_msr_smvm": lambda c, n, m, xs, ys, vs, v: [c.sr.smvm(c.sr.sparse(n, m, _coo(xs, ys, vs)), v)],
+    # :66-67
+    "test_msr_nnz": lambda c, n, m, xs, ys, vs: [c.sr.nnz(c.sr.sparse(n, m, _coo(xs, ys, vs)))],
+    # :74-76
+    "test_msr_coo": lambda c, n, m, xs, ys, vs: list(c.sr.coo(c.sr.sparse(n, m, _coo(xs, ys, vs)))),
+    # :87-89
+    "test_msr_vsmm": lambda c, n, m, v, xs, ys, vs: [c.sr.vsmm(v, c.sr.sparse(n, m, _coo(xs, ys, vs)))],
+    # :114-115
+    "test_msc_eye": lambda c, n, m: [c.sc.dense(c.sc.eye(n, m))],
+    # :126-127
+    "test_msc_sparse": lambda c, n, m, xs, ys, vs: [c.sc.dense(c.sc.sparse(n, m, _coo(xs, ys, vs)))],
+    # :136-137
+    "test_msc_nnz": lambda c, n, m, xs, ys, vs: [c.sc.nnz(c.sc.sparse(n, m, _coo(xs, ys, vs)))],
+    # :144-146
+    "test_msc_coo": lambda c, n, m, xs, ys, vs: list(c.sc.coo(c.sc.sparse(n, m, _coo(xs, ys, vs)))),
+    # :153-155
+    "test_msr_transpose": lambda c, n, m, xs, ys, vs:
+        [c.sc.dense(c.sr.transpose(c.sr.sparse(n, m, _coo(xs, ys, vs))))],
+    # :162-164
+    "test_msc_transpose": lambda c, n, m, xs, ys, vs:
+        [c.sr.dense(c.sc.transpose(c.sc.sparse(n, m, _coo(xs, ys, vs))))],
+}
+
+
 def _decode(item, shape_hint=None):
     ty = {"i64": np.int64, "i32": np.int32}[item["type"]]
     v = item["value"]
@@ -117,8 +195,8 @@ def _decode(item, shape_hint=None):
     return int(v)
 
 
-def load_kat():
-    doc = json.load(open(os.path.join(HERE, "golden", "compressed_kat.json")))
+def load_kat(name="compressed_kat.json"):
+    doc = json.load(open(os.path.join(HERE, "golden", name)))
     out = []
     for c in doc["cases"]:
         out.append((c["entry"], c["ref"], [_decode(i) for i in c["input"]],
@@ -127,7 +205,7 @@ def load_kat():
 
 
 def run_kat(c, entry, inputs):
-    return ENTRIES[entry](c, *inputs)
+    return (ENTRIES.get(entry) or MONO_ENTRIES[entry])(c, *inputs)
 
 
 def assert_kat_equal(got, want, ref):
