@@ -180,10 +180,12 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     SAMD_TRY(slot.get(count));
     K *ks = nullptr;
     const uint32_t *sorted_pay = nullptr;
+    SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 2, 0, sizeof(int64_t), ctx->stream));
     SAMD_TRY((radix_sort_pairs<K, uint32_t>(ctx, keys.p, keys_b.p,
                                              kIndirect ? (const uint32_t *)nullptr
                                                        : reinterpret_cast<const uint32_t *>(vals_in),
-                                             pay_a.p, pay_b.p, count, begin_bit, end_bit, &ks, &sorted_pay)));
+                                             pay_a.p, pay_b.p, count, begin_bit, end_bit, &ks, &sorted_pay,
+                                             (int *)(ctx->d_small + 2))));
     const uint32_t *perm = kIndirect ? sorted_pay : nullptr;
     const T *vs = kIndirect ? vals_in : reinterpret_cast<const T *>(sorted_pay);
 
@@ -194,8 +196,9 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
                                                                   (uint32_t *)ctx->d_small)));
     if (err_flag)
       SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 1, err_flag, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    int64_t host[2];
-    SAMD_TRY(read_small(ctx, ctx->d_small, 2, host));
+    int64_t host[3];
+    SAMD_TRY(read_small(ctx, ctx->d_small, 3, host));
+    if ((int)(host[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
     if ((int)(host[1] & 0xffffffff) != 0)
       return set_error(ctx, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
     merged = (int64_t)(uint32_t)(host[0] & 0xffffffffLL);

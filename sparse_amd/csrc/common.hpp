@@ -113,6 +113,7 @@ struct futhark_context {
   int64_t opt_wide_col = 0;
   int64_t opt_spmv_tile = 0;
   int64_t opt_spmm_algo = 0;
+  int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
   // statistics for futhark_context_report
   int64_t n_entries = 0;

@@ -18,7 +18,7 @@
 //              ballot-based match-any, combine wavefront counters through LDS,
 //              reorder the tile in LDS so each digit's run leaves as one
 //              contiguous burst, write to table offsets.
-// Tile = 256 threads x 16 items (8 when key + payload exceed 12 bytes), read in the (wave, round, lane) order of
+// Tile = 256 threads x 32 / 24 / 16 items for 8- / 12- / 16-byte pairs, read in the (wave, round, lane) order of
 // scan.hpp so every load is a coalesced 64-lane row.
 #pragma once
 
@@ -28,10 +28,16 @@ namespace samd {
 
 constexpr int kRsRadix = 256;
 
-// items per thread: the tile's keys + payloads are re-ordered in LDS (<= 48 KiB of it)
+// items per thread: the tile's keys + payloads are re-ordered in LDS
 template <class K, class P>
 struct RsCfg {
-  static constexpr int kItems = (sizeof(K) + sizeof(P)) <= 12 ? 16 : 8;
+#ifdef SAMD_RS_ITEMS_LAB
+  static constexpr int kItems = SAMD_RS_ITEMS_LAB;
+#else
+  // measured on MI355X (bench/sort_lab.hip, 8.4e7 pairs): 8-byte pairs 16 -> 32 items 2.80 -> 2.20 ms,
+  // 12-byte pairs 16 -> 24 items 5.11 -> 4.20 ms (28 and 32 are slower again): 64-72 KB of LDS per block
+  static constexpr int kItems = (sizeof(K) + sizeof(P)) <= 8 ? 32 : ((sizeof(K) + sizeof(P)) <= 12 ? 24 : 16);
+#endif
   static constexpr int kTile = kBlock * kItems;
 };
 
@@ -134,18 +140,255 @@ __global__ __launch_bounds__(kBlock) void rs_scatter(const K *__restrict__ kin, 
   }
 }
 
+// ---------------------------------------------------------------- one-sweep variant
+// One read of the keys builds the digit histograms of ALL passes (rs_hist_all); each pass is then a
+// single kernel: a tile learns where its digit runs go by looking back over the tiles before it
+// (decoupled look-back on status[tile][digit] words = 2 flag bits + 62-bit count) instead of a
+// per-tile histogram pass and a device-wide scan.  Tiles are handed out through a ticket counter so
+// that every tile a block waits for has already started; a wait that lasts longer than
+// kRsSpinLimit (2 s of the 100 MHz wall clock) poisons the chain and raises *err, so every wave
+// reaches its exit whatever happens.
+constexpr int kRsMaxPasses = 8;
+constexpr unsigned long long kRsFlagAgg = 1ull << 62, kRsFlagIncl = 2ull << 62, kRsFlagPoison = 3ull << 62;
+constexpr unsigned long long kRsValMask = (1ull << 62) - 1;
+constexpr unsigned long long kRsSpinLimit = 200000000ull;
+
+template <class K, int ITEMS>
+__global__ __launch_bounds__(kBlock) void rs_hist_all(const K *__restrict__ keys, uint32_t n, int begin_bit,
+                                                      int end_bit, uint32_t *__restrict__ ghist) {
+  __shared__ uint32_t h[kRsMaxPasses][kRsRadix];
+  for (int d = threadIdx.x; d < kRsMaxPasses * kRsRadix; d += kBlock) (&h[0][0])[d] = 0;
+  __syncthreads();
+  const int passes = (end_bit - begin_bit + 7) / 8;
+  constexpr uint32_t TILE = kBlock * ITEMS;
+  const uint32_t ntiles = (n + TILE - 1) / TILE;
+  for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint32_t base = t * TILE;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const uint32_t i = base + k * kBlock + threadIdx.x;
+      if (i < n) {
+        const K key = keys[i];
+        for (int p = 0; p < passes; p++) {
+          const int shift = begin_bit + 8 * p;
+          const int nb = end_bit - shift < 8 ? end_bit - shift : 8;
+          atomicAdd(&h[p][(uint32_t)(key >> shift) & ((1u << nb) - 1u)], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < passes; p++) {
+    const uint32_t v = h[p][threadIdx.x];
+    if (v) atomicAdd(&ghist[p * kRsRadix + threadIdx.x], v);
+  }
+}
+
+// exclusive scan of each pass's 256 counters, in place (grid = passes)
+__global__ __launch_bounds__(kBlock) void rs_scan_hist(uint32_t *__restrict__ ghist) {
+  __shared__ uint32_t shs[kWaves];
+  uint32_t total;
+  const uint32_t v = ghist[blockIdx.x * kRsRadix + threadIdx.x];
+  const uint32_t ex = block_exclusive_add<uint32_t>(v, shs, total);
+  ghist[blockIdx.x * kRsRadix + threadIdx.x] = ex;
+}
+
+template <class K, class P, int ITEMS, bool IOTA>
+__global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin, const P *__restrict__ pin,
+                                                      K *__restrict__ kout, P *__restrict__ pout, uint32_t n,
+                                                      int shift, uint32_t mask, const uint32_t *__restrict__ gbase,
+                                                      unsigned long long *__restrict__ status,
+                                                      uint32_t *__restrict__ ticket, int *__restrict__ err) {
+  constexpr int TILE = kBlock * ITEMS;
+  __shared__ uint32_t cnt[kWaves][kRsRadix];
+  __shared__ uint32_t lstart[kRsRadix];
+  __shared__ uint32_t goff[kRsRadix];
+  __shared__ uint32_t shs[kWaves];
+  __shared__ uint32_t s_tile;
+  __shared__ int s_fail;
+  __shared__ K skey[TILE];
+  __shared__ P spay[TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    s_tile = atomicAdd(ticket, 1u);
+    s_fail = 0;
+  }
+  for (int d = tid; d < kWaves * kRsRadix; d += kBlock) (&cnt[0][0])[d] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+
+  const uint32_t tile_base = tile * (uint32_t)TILE;
+  const uint32_t base = tile_base + wave * (ITEMS * 64) + lane;
+  K key[ITEMS];
+  P pay[ITEMS];
+  uint32_t rank[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    uint32_t i = base + k * 64;
+    bool ok = i < n;
+    key[k] = ok ? kin[i] : (K)~(K)0;
+    pay[k] = ok ? (IOTA ? (P)i : pin[i]) : (P)0;
+  }
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
+    uint64_t peers = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const uint32_t prev = cnt[wave][d];
+    const uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+    __builtin_amdgcn_wave_barrier();
+    if (r == 0) cnt[wave][d] = prev + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    rank[k] = prev + r;
+  }
+  __syncthreads();
+  uint32_t tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    uint32_t c = cnt[w][tid];
+    cnt[w][tid] = tot;
+    tot += c;
+  }
+  // padding keys of the last tile were counted under digit `mask` of an all-ones key: take them out
+  // of what is published (they are not written either)
+  uint32_t pub = tot;
+  {
+    const uint32_t valid0 = (n - tile_base) < (uint32_t)TILE ? (n - tile_base) : (uint32_t)TILE;
+    if ((uint32_t)tid == mask && valid0 < (uint32_t)TILE) pub = tot - ((uint32_t)TILE - valid0);
+  }
+  uint32_t block_total;
+  const uint32_t ex = block_exclusive_add<uint32_t>(tot, shs, block_total);
+  lstart[tid] = ex;
+
+  // ---- look back over the earlier tiles for digit `tid`
+  unsigned long long excl = 0;
+  unsigned long long *mine = status + (size_t)tile * kRsRadix + tid;
+  if (tile == 0) {
+    __hip_atomic_store(mine, kRsFlagIncl | (unsigned long long)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __hip_atomic_store(mine, kRsFlagAgg | (unsigned long long)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int64_t t = (int64_t)tile - 1;
+    const unsigned long long t0 = wall_clock64();
+    bool fail = false;
+    while (true) {
+      const unsigned long long w =
+          __hip_atomic_load(status + (size_t)t * kRsRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long f = w >> 62;
+      if (f == 0) {
+        if (wall_clock64() - t0 > kRsSpinLimit) { fail = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      if (f == 3) { fail = true; break; }
+      excl += w & kRsValMask;
+      if (f == 2) break;
+      t--;
+    }
+    if (fail) {
+      s_fail = 1;
+      *err = 1;
+      __hip_atomic_store(mine, kRsFlagPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(mine, kRsFlagIncl | (excl + pub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  goff[tid] = gbase[tid] + (uint32_t)excl - ex;
+  __syncthreads();
+  if (s_fail) return;  // uniform: nothing of this tile is written
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
+    const uint32_t p = lstart[d] + cnt[wave][d] + rank[k];
+    skey[p] = key[k];
+    spay[p] = pay[k];
+  }
+  __syncthreads();
+  const uint32_t valid = (n - tile_base) < (uint32_t)TILE ? (n - tile_base) : (uint32_t)TILE;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const uint32_t i = k * kBlock + tid;
+    if (i < valid) {
+      const K kk = skey[i];
+      const uint32_t d = (uint32_t)(kk >> shift) & mask;
+      const uint32_t g = goff[d] + i;
+      kout[g] = kk;
+      pout[g] = spay[i];
+    }
+  }
+}
+
+template <class K, class P>
+int radix_sort_pairs_onesweep(futhark_context *ctx, K *keys_a, K *keys_b, const P *pay_in, P *pay_a, P *pay_b,
+                              int64_t n, int begin_bit, int end_bit, K **keys_out, const P **pay_out, int *err) {
+  constexpr int ITEMS = RsCfg<K, P>::kItems;
+  constexpr int TILE = RsCfg<K, P>::kTile;
+  const uint32_t ntiles = (uint32_t)cdiv(n, TILE);
+  const int passes = (end_bit - begin_bit + 7) / 8;
+  Tmp<uint32_t> ghist(ctx);                 // [passes][256] digit bases, then one ticket counter per pass
+  Tmp<unsigned long long> status(ctx);      // [ntiles][256], cleared before every pass
+  const int64_t gcount = (int64_t)passes * kRsRadix + passes;
+  SAMD_TRY(ghist.get(gcount));
+  SAMD_TRY(status.get((int64_t)ntiles * kRsRadix));
+  SAMD_HIP(ctx, hipMemsetAsync(ghist.p, 0, sizeof(uint32_t) * (size_t)gcount, ctx->stream));
+  {
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+    hipLaunchKernelGGL((rs_hist_all<K, ITEMS>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const K *)keys_a,
+                       (uint32_t)n, begin_bit, end_bit, ghist.p);
+    SAMD_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(rs_scan_hist, dim3(passes), dim3(kBlock), 0, ctx->stream, ghist.p);
+    SAMD_LAUNCH_CHECK(ctx);
+  }
+  K *kin = keys_a, *kout = keys_b;
+  const P *pin = pay_in;
+  P *pout = pay_a, *pspare = pay_b;
+  for (int p = 0; p < passes; p++) {
+    const int shift = begin_bit + 8 * p;
+    const int nb = end_bit - shift < 8 ? end_bit - shift : 8;
+    const uint32_t mask = (1u << nb) - 1u;
+    SAMD_HIP(ctx, hipMemsetAsync(status.p, 0, sizeof(unsigned long long) * (size_t)ntiles * kRsRadix, ctx->stream));
+    const uint32_t *gbase = ghist.p + p * kRsRadix;
+    uint32_t *ticket = ghist.p + passes * kRsRadix + p;
+    if (pin == nullptr)
+      hipLaunchKernelGGL((rs_onesweep<K, P, ITEMS, true>), dim3(ntiles), dim3(kBlock), 0, ctx->stream, (const K *)kin,
+                         pin, kout, pout, (uint32_t)n, shift, mask, gbase, status.p, ticket, err);
+    else
+      hipLaunchKernelGGL((rs_onesweep<K, P, ITEMS, false>), dim3(ntiles), dim3(kBlock), 0, ctx->stream, (const K *)kin,
+                         pin, kout, pout, (uint32_t)n, shift, mask, gbase, status.p, ticket, err);
+    SAMD_LAUNCH_CHECK(ctx);
+    K *tk = kin; kin = kout; kout = tk;
+    P *written = pout;
+    pout = (written == pay_a) ? pspare : pay_a;
+    pin = written;
+  }
+  *keys_out = kin;
+  *pay_out = pin;
+  return 0;
+}
+
 // Sorts n (< 2^32) (key, payload) pairs by key bits [begin_bit, end_bit), stable.
 // keys_a / pay_in are the inputs (pay_in is only read; nullptr = the payload is the
 // element's position, P = uint32_t); keys_b, pay_a, pay_b are scratch of the same length.
 // On return *keys_out / *pay_out point at whichever buffers hold the result (pay_in itself
-// when no pass ran: nullptr then still means "identity").
+// when no pass ran: nullptr then still means "identity").  sort_err: device int the one-sweep
+// variant raises if a look-back wait timed out (the caller reads it at its next synchronisation).
 template <class K, class P>
 int radix_sort_pairs(futhark_context *ctx, K *keys_a, K *keys_b, const P *pay_in, P *pay_a, P *pay_b, int64_t n,
-                     int begin_bit, int end_bit, K **keys_out, const P **pay_out) {
+                     int begin_bit, int end_bit, K **keys_out, const P **pay_out, int *sort_err) {
   constexpr int ITEMS = RsCfg<K, P>::kItems;
   constexpr int TILE = RsCfg<K, P>::kTile;
   if (n >= (int64_t)0xffff0000LL) return set_error(ctx, "sort: more than 2^32 entries on one device");
   const uint32_t ntiles = (uint32_t)cdiv(n, TILE);
+  if (ctx->opt_sort_algo == 0 && n > 0 && end_bit > begin_bit && end_bit - begin_bit <= 8 * kRsMaxPasses)
+    return radix_sort_pairs_onesweep<K, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, begin_bit, end_bit, keys_out,
+                                           pay_out, sort_err);
   K *kin = keys_a, *kout = keys_b;
   const P *pin = pay_in;
   P *pout = pay_a, *pspare = pay_b;
