@@ -484,6 +484,20 @@ int futhark_entry_test_msr_transpose(struct futhark_context *ctx, struct futhark
 int futhark_entry_test_msc_transpose(struct futhark_context *ctx, struct futhark_i32_2d **out0,
                                      SPARSE_AMD_COO_ARGS);
 
+/* ------------------------------------------- (5) Matrix Market loader (host side)
+ * No counterpart in the reference, which has no file format: its inputs only arrive as entry-point
+ * arrays.  SURVEY.md 8(f) row 4: the step in front of `sparse`.  Reads a `coordinate` file
+ * (real | integer | pattern; general | symmetric | skew-symmetric) into 0-based i64 triples in file
+ * order, symmetric files expanded; `threads` > 1 parses the body in parallel.  The three arrays are
+ * malloc'ed: release each with sparse_amd_mtx_free.  On failure returns non-zero and, if `error` is
+ * not NULL, a malloc'ed message the caller frees.  No GPU is touched. */
+int sparse_amd_mtx_read(const char *path, int threads, int64_t *n, int64_t *m, int64_t *count,
+                        int64_t **rows, int64_t **cols, double **vals, char **error);
+/* Writes `coordinate real general` with 17 significant digits (every f64 round-trips). */
+int sparse_amd_mtx_write(const char *path, int64_t n, int64_t m, int64_t count, const int64_t *rows,
+                         const int64_t *cols, const double *vals, char **error);
+void sparse_amd_mtx_free(void *p);
+
 /* ------------------------------------------------- (3) context extensions
  * No counterpart in the generated API. */
 /* Run all subsequent work on the caller's HIP stream (hipStream_t); the context

@@ -10,6 +10,7 @@
 #include "spmm.hpp"
 #include "convert.hpp"
 #include "mono.hpp"
+#include "mtx.hpp"
 
 using namespace samd;
 
@@ -1167,5 +1168,33 @@ int futhark_entry_test_msc_transpose(CTX, mat_i32 **out0, COO_ARGS) {
   m_free(ctx, a);
   return rc;
 }
+
+// ------------------------------------------------------ Matrix Market (host side)
+int sparse_amd_mtx_read(const char *path, int threads, int64_t *n, int64_t *m, int64_t *count, int64_t **rows,
+                        int64_t **cols, double **vals, char **error) {
+  MtxResult r;
+  std::string err;
+  if (error) *error = nullptr;
+  if (mtx_read(path, threads, &r, &err) != 0) {
+    if (error) *error = strdup(err.c_str());
+    return 1;
+  }
+  *n = r.n; *m = r.m; *count = r.count;
+  *rows = r.rows; *cols = r.cols; *vals = r.vals;
+  return 0;
+}
+
+int sparse_amd_mtx_write(const char *path, int64_t n, int64_t m, int64_t count, const int64_t *rows,
+                         const int64_t *cols, const double *vals, char **error) {
+  std::string err;
+  if (error) *error = nullptr;
+  if (mtx_write(path, n, m, count, rows, cols, vals, &err) != 0) {
+    if (error) *error = strdup(err.c_str());
+    return 1;
+  }
+  return 0;
+}
+
+void sparse_amd_mtx_free(void *p) { free(p); }
 
 }  // extern "C"

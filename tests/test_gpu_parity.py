@@ -393,3 +393,19 @@ def test_c_harness_written_against_generated_api(ctx):
     out = subprocess.run([exe], capture_output=True, timeout=100)
     assert out.returncode == 0, out.stderr.decode()
     assert b"harness ok" in out.stdout
+
+
+def test_matrix_market_file_to_spmv(ctx, tmp_path):
+    """File -> triples (C++ loader) -> sparse -> smvm, against the oracle fed from the same file."""
+    from sparse_amd.io import read_mtx, write_mtx
+    O, M = Oracle("f64"), mk(ctx, "f64")
+    n, m = 3000, 2500
+    r, c, v = random_coo(n, m, 40000, "f64", seed=12)
+    p = tmp_path / "a.mtx"
+    write_mtx(p, n, m, (r, c, v))
+    nn, mm, coo = read_mtx(p, threads=4)
+    assert (nn, mm) == (n, m)
+    A = M.sr.sparse(nn, mm, coo)
+    assert_same_record(A, O.sr_sparse(n, m, r, c, v))
+    x = synth.uniform_values(2, m, "f64")
+    close(M.sr.smvm(A, x), O.sr_smvm(O.sr_sparse(n, m, r, c, v), x), "f64")
