@@ -902,15 +902,15 @@ int main(int argc, char **argv) {
 
   std::vector<Variant> vs;
   vs.push_back({"shipped stream (spmv.hpp) 1024", [&] {
-                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024>), dim3((unsigned)nt1k), dim3(256), 0, st,
+                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024, false>), dim3((unsigned)nt1k), dim3(256), 0, st,
                                      (const int64_t *)row_ptr, (const int32_t *)col, (const double *)val,
                                      (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k, 0);
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, 1024>), dim3((unsigned)((nt1k - 1 + 255) / 256)),
                                      dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)lb1k,
-                                     (const double *)hd1k, y, nt1k);
+                                     (const double *)hd1k, y, nt1k, false);
                 }, true, {}});
   vs.push_back({"shipped, no fixup launch", [&] {
-                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024>), dim3((unsigned)nt1k), dim3(256), 0, st,
+                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024, false>), dim3((unsigned)nt1k), dim3(256), 0, st,
                                      (const int64_t *)row_ptr, (const int32_t *)col, (const double *)val,
                                      (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k, 0);
                 }, false, {}});
@@ -926,7 +926,7 @@ int main(int argc, char **argv) {
                                      (const double *)x, y, (const int64_t *)LB, HD, nnz, NT);                        \
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, TILE>), dim3((unsigned)((NT - 1 + 255) / 256)),      \
                                      dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)LB,                \
-                                     (const double *)HD, y, NT);                                                     \
+                                     (const double *)HD, y, NT, false);                                                     \
                 }, true, {}})
   V1(2048, 2, lb2k, hd2k, nt2k);
   V1(4096, 4, lb4k, hd4k, nt4k);
@@ -940,7 +940,7 @@ int main(int argc, char **argv) {
                                      (const double *)x, y, (const int64_t *)LB, HD, nnz, NT_);                       \
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, TILE>), dim3((unsigned)((NT_ - 1 + 255) / 256)),     \
                                      dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)LB,                \
-                                     (const double *)HD, y, NT_);                                                    \
+                                     (const double *)HD, y, NT_, false);                                                    \
                 }, CHECK, {}})
   V2(2048, 2, false, true, true, lb2k, hd2k, nt2k, true);
   V2(2048, 2, true, true, true, lb2k, hd2k, nt2k, true);
@@ -958,7 +958,7 @@ int main(int argc, char **argv) {
                                      (const double *)x, y, (const int64_t *)LB, HD, nnz, NT_);                       \
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, TILE>), dim3((unsigned)((NT_ - 1 + 255) / 256)),     \
                                      dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)LB,                \
-                                     (const double *)HD, y, NT_);                                                    \
+                                     (const double *)HD, y, NT_, false);                                                    \
                 }, true, {}})
   V3(2048, 2, false, 2048, lb2k, hd2k, nt2k);
   V3(2048, 2, true, 2048, lb2k, hd2k, nt2k);
@@ -976,7 +976,7 @@ int main(int argc, char **argv) {
                                      (const double *)x, y, (const int64_t *)LB, HD, nnz, NT_);                       \
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, TILE>), dim3((unsigned)((NT_ - 1 + 255) / 256)),     \
                                      dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)LB,                \
-                                     (const double *)HD, y, NT_);                                                    \
+                                     (const double *)HD, y, NT_, false);                                                    \
                 }, true, {}})
   V4(1024, false, lb1k, hd1k, nt1k);
   V4(1024, true, lb1k, hd1k, nt1k);
@@ -991,7 +991,7 @@ int main(int argc, char **argv) {
                                      (const double *)x, y, (const int64_t *)LB, HD, nnz, NT_);                       \
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, TILE>), dim3((unsigned)((NT_ - 1 + 255) / 256)),     \
                                      dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)LB,                \
-                                     (const double *)HD, y, NT_);                                                    \
+                                     (const double *)HD, y, NT_, false);                                                    \
                 }, true, {}})
   V5(1024, 4, false, 0, lb1k, hd1k, nt1k);
   V5(1024, 8, false, 0, lb1k, hd1k, nt1k);
@@ -1008,7 +1008,7 @@ int main(int argc, char **argv) {
                                      (const double *)x, y, (const int64_t *)LB, HD, nnz, NT_, g);                    \
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, TILE>), dim3((unsigned)((NT_ - 1 + 255) / 256)),     \
                                      dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)LB,                \
-                                     (const double *)HD, y, NT_);                                                    \
+                                     (const double *)HD, y, NT_, false);                                                    \
                 }, CHECK, {}})
   V6(1024, 256, true, true, false, lb1k, hd1k, nt1k, true);
   V6(1024, 256, false, true, false, lb1k, hd1k, nt1k, false);
@@ -1028,7 +1028,7 @@ int main(int argc, char **argv) {
                                      (const double *)x, y, (const int64_t *)LB, HD, nnz, NT_);                       \
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, TILE>), dim3((unsigned)((NT_ - 1 + 255) / 256)),     \
                                      dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)LB,                \
-                                     (const double *)HD, y, NT_);                                                    \
+                                     (const double *)HD, y, NT_, false);                                                    \
                 }, true, {}})
   V7(1024, false, false, false, lb1k, hd1k, nt1k);
   V7(1024, true, false, false, lb1k, hd1k, nt1k);

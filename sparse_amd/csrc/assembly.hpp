@@ -124,6 +124,8 @@ __global__ __launch_bounds__(kBlock) void merge_emit_kernel(const K *__restrict_
 }
 
 // ---------------------------------------------------------------------- plan
+// tile_lb[ntiles + 1] (zeroed by the caller) receives the longest first spill: the largest
+// number of entries by which a row runs past the end of the tile it starts in.
 __global__ __launch_bounds__(kBlock) void plan_kernel(const int64_t *__restrict__ row_ptr, int64_t n, int64_t tile,
                                                       int64_t ntiles, int64_t *__restrict__ tile_lb) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -136,6 +138,11 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(const int64_t *__restrict_
     if (row_ptr[mid] >= target) hi = mid; else lo = mid + 1;
   }
   tile_lb[t] = lo;
+  if (t > 0 && lo > 0) {
+    const int64_t rs = row_ptr[lo - 1], re = row_ptr[lo];
+    if (re > target && rs >= target - tile)  // row lo-1 starts in tile t-1 and runs into tile t
+      atomicMax(reinterpret_cast<unsigned long long *>(&tile_lb[ntiles + 1]), (unsigned long long)(re - target));
+  }
 }
 
 constexpr int64_t kPlanTile = 1024;  // entries per tile; matches the SpMV kernels' TILE
@@ -144,8 +151,10 @@ template <class T>
 int build_plan(futhark_context *ctx, CsrBody<T> *b) {
   b->tile = kPlanTile;
   b->ntiles = cdiv(b->nnz, b->tile);
-  SAMD_TRY(dalloc(ctx, &b->tile_lb, b->ntiles + 1));
+  SAMD_TRY(dalloc(ctx, &b->tile_lb, b->ntiles + 2));
   SAMD_TRY(dalloc(ctx, &b->head, b->ntiles));
+  SAMD_HIP(ctx, hipMemsetAsync(b->tile_lb + b->ntiles + 1, 0, sizeof(int64_t), ctx->stream));
+  b->spill_max = -1;
   hipLaunchKernelGGL(plan_kernel, dim3((unsigned)cdiv(b->ntiles + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                      (const int64_t *)b->row_ptr, b->n, b->tile, b->ntiles, b->tile_lb);
   SAMD_LAUNCH_CHECK(ctx);

@@ -228,6 +228,7 @@ struct CsrBody {
   int64_t *tile_lb = nullptr;
   T *head = nullptr;
   int64_t max_row_len = -1;  // filled lazily by the SpMV dispatcher
+  mutable int64_t spill_max = -1;  // longest first spill (tile_lb[ntiles+1]); read lazily, small matrices only
   int refs = 1;
 };
 

@@ -21,7 +21,9 @@
 //   * a row that starts in tile t is written by tile t (plain/non-temporal store).
 //     The part of a row that spills into later tiles is written to head[t'] by those
 //     tiles and added in tile order by spmv_fixup: no atomics, so y is
-//     bit-reproducible run to run.
+//     bit-reproducible run to run.  Records of at most kInlineMaxTiles tiles (launch-bound)
+//     use the INLINE variant: the owner fetches a spill of <= kSpillInline entries with its
+//     tile and finishes the row, and the fix-up launch is skipped when no row spills further.
 //   * blockIdx -> tile is XCD-aware: the 8 XCDs (blocks b, b+8, ... share one)
 //     each take a contiguous eighth of the tiles, so the x window a row block
 //     gathers is cached in one XCD's L2 instead of all eight.
@@ -37,6 +39,8 @@
 namespace samd {
 
 constexpr int kSpmvTile = (int)kPlanTile;  // entries per block
+constexpr int kSpillInline = 64;           // INLINE: a row running at most this far past its tile is finished by its owner
+constexpr int64_t kInlineMaxTiles = 4096;  // INLINE is used below this many tiles (launch-bound sizes)
 
 typedef unsigned int raw16 __attribute__((ext_vector_type(4)));  // one 128-bit load/store
 
@@ -54,16 +58,16 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nblocks) {
   return start + (bid >> 3);
 }
 
-template <class T, class I, int TILE>
+template <class T, class I, int TILE, bool INLINE>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__restrict__ row_ptr,
                                                              const I *__restrict__ col, const T *__restrict__ val,
                                                              const T *__restrict__ x, T *__restrict__ y,
                                                              const int64_t *__restrict__ tile_lb,
                                                              T *__restrict__ head, int64_t nnz, int64_t ntiles,
                                                              int force_lanes) {
-  __shared__ __attribute__((aligned(16))) T sval[TILE];
-  __shared__ __attribute__((aligned(16))) I scol[TILE];
-  __shared__ int longrows[TILE / 16 + 2];
+  __shared__ __attribute__((aligned(16))) T sval[TILE + (INLINE ? kSpillInline : 0)];
+  __shared__ __attribute__((aligned(16))) I scol[TILE + (INLINE ? kSpillInline : 0)];
+  __shared__ int longrows[TILE / 16 + 6];
   __shared__ int nlong;
 
   const int tid = threadIdx.x;
@@ -95,6 +99,20 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
     }
   }
 
+  // ---- INLINE: a short spill of the last row that starts here is fetched along with the tile
+  const int64_t lim = base + cnt;
+  int64_t lim2 = lim;
+  if (INLINE && lb1 > lb0) {
+    const int64_t sp = row_ptr[lb1] - lim;  // uniform over the block
+    if (sp > 0 && sp <= kSpillInline) {
+      lim2 = lim + sp;
+      if (tid < sp) {
+        scol[TILE + tid] = col[lim + tid];
+        sval[TILE + tid] = val[lim + tid];
+      }
+    }
+  }
+
   // ---- rows of this tile: the candidate head row (lb0-1) and the rows that start here
   const int64_t rfirst = lb0 > 0 ? lb0 - 1 : 0;
   const int nrows = (int)(lb1 - rfirst);
@@ -114,15 +132,17 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
   __syncthreads();
 
   // ---- phase 2: L lanes per row fragment, row-major gather of x
-  const int64_t lim = base + cnt;
   for (int j = grp; j < nrows; j += ngrp) {
     const int64_t r = rfirst + j;
     int64_t rs, re;
     if (j == grp) { rs = rs0; re = re0; }
     else { rs = ntload(&row_ptr[r]); re = ntload(&row_ptr[r + 1]); }
-    if (r < lb0 && re <= base) continue;  // candidate head row does not reach this tile
+    if (r < lb0) {
+      if (re <= base) continue;                                              // candidate head row does not reach this tile
+      if (INLINE && re - (rs / TILE + 1) * TILE <= kSpillInline) continue;   // ... or was finished by its owner
+    }
     const int s = (int)((rs > base ? rs : base) - base);
-    const int e = (int)((re < lim ? re : lim) - base);
+    const int e = (int)((re < lim2 ? re : lim2) - base);
     if (e - s > 16 * L) {
       if (sub == 0) {
         const int slot = atomicAdd(&nlong, 1);
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
     const int64_t r = rfirst + longrows[i];
     const int64_t rs = row_ptr[r], re = row_ptr[r + 1];
     const int s = (int)((rs > base ? rs : base) - base);
-    const int e = (int)((re < lim ? re : lim) - base);
+    const int e = (int)((re < lim2 ? re : lim2) - base);
     T acc = (T)0;
     for (int q = s + lane; q < e; q += 4 * 64) {
       T xv[4], av[4];
@@ -188,7 +208,7 @@ template <class T, int TILE>
 __global__ __launch_bounds__(kBlock) void spmv_fixup_kernel(const int64_t *__restrict__ row_ptr,
                                                             const int64_t *__restrict__ tile_lb,
                                                             const T *__restrict__ head, T *__restrict__ y,
-                                                            int64_t ntiles) {
+                                                            int64_t ntiles, bool inline_spills) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x + 1;
   if (t >= ntiles) return;
   const int64_t lb = tile_lb[t];
@@ -198,6 +218,7 @@ __global__ __launch_bounds__(kBlock) void spmv_fixup_kernel(const int64_t *__res
   const int64_t re = row_ptr[lb];
   if (re <= base) return;                  // no fragment enters this tile
   if (row_ptr[r] < base - TILE) return;    // an earlier tile is this row's first spill
+  if (inline_spills && re - base <= kSpillInline) return;  // finished by its owner inside spmv_stream
   T acc = y[r];
   for (int64_t u = t; u < ntiles && u * TILE < re; u++) acc = (T)(acc + head[u]);
   y[r] = acc;
@@ -229,14 +250,25 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     if (a->tile != kSpmvTile) return set_error(ctx, "spmv: plan tile mismatch");
     int force = (int)ctx->opt_spmv_lanes;
     if (force < 0 || force > 64 || (force & (force - 1))) return set_error(ctx, "spmv: spmv_lanes must be a power of two <= 64");
-    hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile>), dim3((unsigned)a->ntiles), dim3(kBlock), 0, ctx->stream,
-                       (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y, (const int64_t *)a->tile_lb,
-                       a->head, a->nnz, a->ntiles, force);
+    // Small records are launch-bound: there the owner tile finishes short spills itself and the fix-up
+    // launch is dropped when no row spills far.  Large records keep the fix-up launch (measured faster:
+    // C2 0.238 vs 0.244 ms), so nothing is read back for them.
+    const bool inl = a->ntiles > 1 && a->ntiles <= kInlineMaxTiles;
+    if (inl && a->spill_max < 0)  // first product with this record: one small read, then cached
+      SAMD_TRY(read_small(ctx, a->tile_lb + a->ntiles + 1, 1, &a->spill_max));
+    if (inl)
+      hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, true>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
+                         ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y,
+                         (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force);
+    else
+      hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, false>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
+                         ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y,
+                         (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force);
     SAMD_LAUNCH_CHECK(ctx);
-    if (a->ntiles > 1) {
+    if (a->ntiles > 1 && !(inl && a->spill_max <= kSpillInline)) {
       hipLaunchKernelGGL((spmv_fixup_kernel<T, kSpmvTile>), dim3((unsigned)cdiv(a->ntiles - 1, kBlock)), dim3(kBlock),
                          0, ctx->stream, (const int64_t *)a->row_ptr, (const int64_t *)a->tile_lb,
-                         (const T *)a->head, y, a->ntiles);
+                         (const T *)a->head, y, a->ntiles, inl);
       SAMD_LAUNCH_CHECK(ctx);
     }
     return 0;
