@@ -855,6 +855,140 @@ __global__ __launch_bounds__(kBlock) void spmv_v7(const int64_t *__restrict__ ro
   }
 }
 
+
+// ---- compact-index variant: 16-bit tile-relative column offsets + 16-bit row starts within the tile
+__global__ __launch_bounds__(kBlock) void build_col16(const int32_t *__restrict__ col, int64_t nnz, int64_t ntiles,
+                                                      uint16_t *__restrict__ col16, int32_t *__restrict__ c0s,
+                                                      int *__restrict__ fail) {
+  __shared__ int smin[kWaves], smax[kWaves];
+  const int64_t t = blockIdx.x, base = t * 1024;
+  int mn = 0x7fffffff, mx = -1;
+  int c[4];
+  for (int k = 0; k < 4; k++) {
+    const int64_t e = base + k * kBlock + threadIdx.x;
+    c[k] = e < nnz ? col[e] : -1;
+    if (c[k] >= 0) { mn = c[k] < mn ? c[k] : mn; mx = c[k] > mx ? c[k] : mx; }
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int a = __shfl_xor(mn, d, 64), b = __shfl_xor(mx, d, 64);
+    mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  mn = smin[0]; mx = smax[0];
+  for (int w = 1; w < kWaves; w++) { mn = smin[w] < mn ? smin[w] : mn; mx = smax[w] > mx ? smax[w] : mx; }
+  if (threadIdx.x == 0) { c0s[t] = mn; if (mx - mn > 65535) *fail = 1; }
+  for (int k = 0; k < 4; k++) {
+    const int64_t e = base + k * kBlock + threadIdx.x;
+    if (e < nnz) col16[e] = (uint16_t)(c[k] - mn);
+  }
+}
+
+__global__ void build_r16(const int64_t *__restrict__ row_ptr, int64_t n, uint16_t *__restrict__ r16) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r < n) r16[r] = (uint16_t)(row_ptr[r] & 1023);
+}
+
+template <bool NTX, int U, int WPE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void spmv_c16(const int64_t *__restrict__ row_ptr, const uint16_t *__restrict__ r16,
+                                                   const uint16_t *__restrict__ col16, const int32_t *__restrict__ c0s,
+                                                   const double *__restrict__ val, const double *__restrict__ x,
+                                                   double *__restrict__ y, const int64_t *__restrict__ tile_lb,
+                                                   double *__restrict__ head, int64_t nnz, int64_t ntiles) {
+  constexpr int TILE = 1024;
+  typedef double T;
+  __shared__ __attribute__((aligned(16))) T sval[TILE];
+  __shared__ __attribute__((aligned(16))) uint16_t scol[TILE];
+  __shared__ int longrows[TILE / 16 + 2];
+  __shared__ int nlong;
+  const int tid = threadIdx.x;
+  const int64_t t = xcd_remap(blockIdx.x, ntiles);
+  const int64_t base = t * TILE;
+  const int cnt = (int)((nnz - base) < (int64_t)TILE ? (nnz - base) : (int64_t)TILE);
+  const int64_t lb0 = tile_lb[t], lb1 = tile_lb[t + 1];
+  const int c0 = c0s[t];
+  const int64_t S1 = row_ptr[lb1];
+  if (cnt == TILE) {
+    raw16 a[2], c;
+    const raw16 *cp = reinterpret_cast<const raw16 *>(col16 + base);
+    const raw16 *vp = reinterpret_cast<const raw16 *>(val + base);
+    if (tid < 128) c = ntload(cp + tid);
+    a[0] = ntload(vp + tid);
+    a[1] = ntload(vp + kBlock + tid);
+    if (tid < 128) reinterpret_cast<raw16 *>(scol)[tid] = c;
+    reinterpret_cast<raw16 *>(sval)[tid] = a[0];
+    reinterpret_cast<raw16 *>(sval)[kBlock + tid] = a[1];
+  } else {
+    for (int e = tid; e < cnt; e += kBlock) { scol[e] = col16[base + e]; sval[e] = val[base + e]; }
+  }
+  const int64_t rfirst = lb0 > 0 ? lb0 - 1 : 0;
+  const int nrows = (int)(lb1 - rfirst);
+  int L = 1;
+  {
+    const int avg4 = cnt / (nrows > 0 ? nrows : 1) / 4;
+    while (L < 64 && L * 2 <= avg4) L *= 2;
+  }
+  if (tid == 0) nlong = 0;
+  const int grp = tid / L, sub = tid & (L - 1), ngrp = kBlock / L;
+  auto startf = [&](int64_t r) -> int64_t { return r < lb1 ? base + (int64_t)ntload(&r16[r]) : S1; };
+  int64_t rs0 = 0, re0 = 0;
+  if (grp < nrows) {
+    const int64_t r = rfirst + grp;
+    rs0 = r < lb0 ? base - 1 : startf(r);
+    re0 = startf(r + 1);
+  }
+  __syncthreads();
+  const int64_t lim = base + cnt;
+  for (int j = grp; j < nrows; j += ngrp) {
+    const int64_t r = rfirst + j;
+    int64_t rs, re;
+    if (j == grp) { rs = rs0; re = re0; }
+    else { rs = r < lb0 ? base - 1 : startf(r); re = startf(r + 1); }
+    if (r < lb0 && re <= base) continue;
+    const int s = (int)((rs > base ? rs : base) - base);
+    const int e = (int)((re < lim ? re : lim) - base);
+    if (e - s > 16 * L) {
+      if (sub == 0) { const int slot = atomicAdd(&nlong, 1); longrows[slot] = j; }
+      continue;
+    }
+    T acc = (T)0;
+    for (int q = s + sub; q < e; q += U * L) {
+      T xv[U], av[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int qq = q + u * L;
+        const bool ok = qq < e;
+        const int cc = c0 + (int)scol[ok ? qq : s];
+        av[u] = ok ? sval[qq] : (T)0;
+        xv[u] = ok ? (NTX ? x[cc] : x[cc]) : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) acc = (T)(acc + (T)(av[u] * xv[u]));
+    }
+    for (int d = L >> 1; d >= 1; d >>= 1) acc = (T)(acc + wshfl_xor(acc, d));
+    if (sub == 0) {
+      if (rs >= base) __builtin_nontemporal_store(acc, &y[r]);
+      else head[t] = acc;
+    }
+  }
+  __syncthreads();
+  const int nl = nlong;
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int i = wave; i < nl; i += kWaves) {
+    const int64_t r = rfirst + longrows[i];
+    const int64_t rs = r < lb0 ? base - 1 : startf(r), re = startf(r + 1);
+    const int s = (int)((rs > base ? rs : base) - base);
+    const int e = (int)((re < lim ? re : lim) - base);
+    T acc = (T)0;
+    for (int q = s + lane; q < e; q += 64) acc = (T)(acc + (T)(sval[q] * x[c0 + (int)scol[q]]));
+    acc = wave_reduce(acc, OpAdd());
+    if (lane == 0) {
+      if (rs >= base) y[r] = acc;
+      else head[t] = acc;
+    }
+  }
+}
+
 struct Variant {
   const char *name;
   std::function<void()> run;
@@ -883,7 +1017,8 @@ int main(int argc, char **argv) {
 
   auto make_plan = [&](int64_t tile, int64_t **lb, double **head) {
     const int64_t nt = (nnz + tile - 1) / tile;
-    CK(hipMalloc(lb, 8 * (nt + 1)));
+    CK(hipMalloc(lb, 8 * (nt + 2)));
+    CK(hipMemsetAsync(*lb, 0, 8 * (nt + 2), st));
     CK(hipMalloc(head, 8 * nt));
     hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((nt + 1 + 255) / 256)), dim3(256), 0, st, (const int64_t *)row_ptr,
                        n, tile, nt, *lb);
@@ -902,7 +1037,55 @@ int main(int argc, char **argv) {
 
   std::vector<Variant> vs;
   vs.push_back({"shipped stream (spmv.hpp) 1024", [&] {
-                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024, false>), dim3((unsigned)nt1k), dim3(256), 0, st,
+                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024, false, 8>), dim3((unsigned)nt1k), dim3(256), 0, st,
+                                     (const int64_t *)row_ptr, (const int32_t *)col, (const double *)val,
+                                     (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k, 0);
+                  hipLaunchKernelGGL((spmv_fixup_kernel<double, 1024>), dim3((unsigned)((nt1k - 1 + 255) / 256)),
+                                     dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)lb1k,
+                                     (const double *)hd1k, y, nt1k, false);
+                }, true, {}});
+  // compact indices
+  uint16_t *col16, *r16;
+  int32_t *c0s;
+  int *cfail;
+  CK(hipMalloc(&col16, 2 * nnz));
+  CK(hipMalloc(&r16, 2 * (n + 1)));
+  CK(hipMalloc(&c0s, 4 * nt1k));
+  CK(hipMalloc(&cfail, 4));
+  CK(hipMemsetAsync(cfail, 0, 4, st));
+  hipLaunchKernelGGL(build_col16, dim3((unsigned)nt1k), dim3(256), 0, st, (const int32_t *)col, nnz, nt1k, col16, c0s, cfail);
+  hipLaunchKernelGGL(build_r16, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, (const int64_t *)row_ptr, n + 1, r16);
+  {
+    int hf;
+    CK(hipMemcpy(&hf, cfail, 4, hipMemcpyDeviceToHost));
+    printf("compact build: %s\n", hf ? "SPAN TOO WIDE" : "ok");
+  }
+#define C16(U, WPE)                                                                                                 \
+  vs.push_back({"c16 compact U=" #U " wpe=" #WPE, [&] {                                                              \
+                  hipLaunchKernelGGL((spmv_c16<false, U, WPE>), dim3((unsigned)nt1k), dim3(256), 0, st,              \
+                                     (const int64_t *)row_ptr, (const uint16_t *)r16, (const uint16_t *)col16,       \
+                                     (const int32_t *)c0s, (const double *)val, (const double *)x, y,                \
+                                     (const int64_t *)lb1k, hd1k, nnz, nt1k);                                        \
+                  hipLaunchKernelGGL((spmv_fixup_kernel<double, 1024>), dim3((unsigned)((nt1k - 1 + 255) / 256)),    \
+                                     dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)lb1k,              \
+                                     (const double *)hd1k, y, nt1k, false);                                          \
+                }, true, {}})
+  C16(8, 1);
+  C16(8, 8);
+  C16(6, 1);
+  C16(6, 8);
+  C16(4, 1);
+  C16(5, 8);
+  vs.push_back({"shipped stream U=6", [&] {
+                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024, false, 6>), dim3((unsigned)nt1k), dim3(256), 0, st,
+                                     (const int64_t *)row_ptr, (const int32_t *)col, (const double *)val,
+                                     (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k, 0);
+                  hipLaunchKernelGGL((spmv_fixup_kernel<double, 1024>), dim3((unsigned)((nt1k - 1 + 255) / 256)),
+                                     dim3(256), 0, st, (const int64_t *)row_ptr, (const int64_t *)lb1k,
+                                     (const double *)hd1k, y, nt1k, false);
+                }, true, {}});
+  vs.push_back({"shipped stream U=5", [&] {
+                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024, false, 5>), dim3((unsigned)nt1k), dim3(256), 0, st,
                                      (const int64_t *)row_ptr, (const int32_t *)col, (const double *)val,
                                      (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k, 0);
                   hipLaunchKernelGGL((spmv_fixup_kernel<double, 1024>), dim3((unsigned)((nt1k - 1 + 255) / 256)),
@@ -910,7 +1093,7 @@ int main(int argc, char **argv) {
                                      (const double *)hd1k, y, nt1k, false);
                 }, true, {}});
   vs.push_back({"shipped, no fixup launch", [&] {
-                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024, false>), dim3((unsigned)nt1k), dim3(256), 0, st,
+                  hipLaunchKernelGGL((spmv_stream_kernel<double, int32_t, 1024, false, 8>), dim3((unsigned)nt1k), dim3(256), 0, st,
                                      (const int64_t *)row_ptr, (const int32_t *)col, (const double *)val,
                                      (const double *)x, y, (const int64_t *)lb1k, hd1k, nnz, nt1k, 0);
                 }, false, {}});

@@ -58,7 +58,28 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nblocks) {
   return start + (bid >> 3);
 }
 
-template <class T, class I, int TILE, bool INLINE>
+// lane `sub` of L: sum of entries s+sub, s+sub+L, ... below e, U gathers in flight
+template <class T, class I, int U>
+__device__ __forceinline__ T row_partial(const T *sval, const I *scol, const T *__restrict__ x, int s, int e, int sub,
+                                         int L) {
+  T acc = (T)0;
+  for (int q = s + sub; q < e; q += U * L) {
+    T xv[U], av[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int qq = q + u * L;
+      const bool ok = qq < e;
+      const I cc = scol[ok ? qq : s];
+      av[u] = ok ? sval[qq] : (T)0;
+      xv[u] = ok ? x[cc] : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) acc = (T)(acc + (T)(av[u] * xv[u]));
+  }
+  return acc;
+}
+
+template <class T, class I, int TILE, bool INLINE, int U>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__restrict__ row_ptr,
                                                              const I *__restrict__ col, const T *__restrict__ val,
                                                              const T *__restrict__ x, T *__restrict__ y,
@@ -122,6 +143,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
     while (L < 64 && L * 2 <= avg4) L *= 2;
     if (force_lanes > 0) L = force_lanes;  // test / tuning override (power of two <= 64)
   }
+
   if (tid == 0) nlong = 0;
   const int grp = tid / L, sub = tid & (L - 1), ngrp = kBlock / L;
   int64_t rs0 = 0, re0 = 0;  // first row's bounds, requested before the barrier
@@ -150,20 +172,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
       }
       continue;
     }
-    T acc = (T)0;
-    for (int q = s + sub; q < e; q += 8 * L) {
-      T xv[8], av[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int qq = q + u * L;
-        const bool ok = qq < e;
-        const I cc = scol[ok ? qq : s];
-        av[u] = ok ? sval[qq] : (T)0;
-        xv[u] = ok ? x[cc] : (T)0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) acc = (T)(acc + (T)(av[u] * xv[u]));
-    }
+    // entries in flight per lane: as many as a typical fragment needs, no more (predicated-off slots
+    // still cost issue slots); U is chosen per record on the host from its mean row length
+    T acc = row_partial<T, I, U>(sval, scol, x, s, e, sub, L);
     for (int d = L >> 1; d >= 1; d >>= 1) acc = (T)(acc + wshfl_xor(acc, d));
     if (sub == 0) {
       if (rs >= base) __builtin_nontemporal_store(acc, &y[r]);
@@ -256,14 +267,22 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     const bool inl = a->ntiles > 1 && a->ntiles <= kInlineMaxTiles;
     if (inl && a->spill_max < 0)  // first product with this record: one small read, then cached
       SAMD_TRY(read_small(ctx, a->tile_lb + a->ntiles + 1, 1, &a->spill_max));
-    if (inl)
-      hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, true>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
-                         ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y,
-                         (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force);
-    else
-      hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, false>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
-                         ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y,
-                         (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force);
+    // gathers in flight per lane: what a typical row fragment needs (mean row length over the lanes it gets)
+    int unroll = 8;
+    {
+      const int64_t avg = a->n > 0 ? a->nnz / a->n : 0;
+      int L = 1;
+      while (L < 64 && L * 2 <= avg / 4) L *= 2;
+      const int64_t per_lane = (avg + L - 1) / L;
+      unroll = per_lane <= 6 ? 6 : 8;
+    }
+#define SAMD_SPMV_LAUNCH(INL, UU)                                                                                  \
+  hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, INL, UU>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,   \
+                     ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y,                      \
+                     (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force)
+    if (inl) { if (unroll == 6) SAMD_SPMV_LAUNCH(true, 6); else SAMD_SPMV_LAUNCH(true, 8); }
+    else { if (unroll == 6) SAMD_SPMV_LAUNCH(false, 6); else SAMD_SPMV_LAUNCH(false, 8); }
+#undef SAMD_SPMV_LAUNCH
     SAMD_LAUNCH_CHECK(ctx);
     if (a->ntiles > 1 && !(inl && a->spill_max <= kSpillInline)) {
       hipLaunchKernelGGL((spmv_fixup_kernel<T, kSpmvTile>), dim3((unsigned)cdiv(a->ntiles - 1, kBlock)), dim3(kBlock),
