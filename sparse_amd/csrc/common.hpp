@@ -113,6 +113,7 @@ struct futhark_context {
   int64_t opt_wide_col = 0;
   int64_t opt_spmv_tile = 0;
   int64_t opt_spmm_algo = 0;
+  int64_t opt_spmv_reorder = 0;  // 0 auto, 1 always (when the record qualifies by size), -1 never
   int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
   // statistics for futhark_context_report
@@ -229,6 +230,11 @@ struct CsrBody {
   T *head = nullptr;
   int64_t max_row_len = -1;  // filled lazily by the SpMV dispatcher
   mutable int64_t spill_max = -1;  // longest first spill (tile_lb[ntiles+1]); read lazily, small matrices only
+  // hot-column renumbering for gather-bound SpMV (spmv.hpp, "reorder"); built lazily, owned by the record
+  mutable int reorder_state = 0;   // 0 undecided, 1 active, -1 rejected
+  mutable int32_t *col_hot = nullptr;    // [nnz] rank of each entry's column by popularity
+  mutable uint32_t *hot_perm = nullptr;  // [m]   hot_perm[rank] = column
+  mutable T *x_hot = nullptr;            // [m]   x gathered into rank order, rewritten by every product
   int refs = 1;
 };
 
@@ -242,6 +248,9 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->vals);
   dfree(ctx, b->tile_lb);
   dfree(ctx, b->head);
+  dfree(ctx, b->col_hot);
+  dfree(ctx, b->hot_perm);
+  dfree(ctx, b->x_hot);
   delete b;
 }
 

@@ -253,6 +253,141 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(const int64_t *__re
   }
 }
 
+// ------------------------------------------------------------------ reorder
+// Power-law matrices (C3: RMAT) are bound by the x gather, not by streaming A: measured on MI355X
+// 19 % L1 and 59 % L2 hit rate, 504 cycles mean L1->L2 read latency, 7.5 GB fetched for 2.6 GB of
+// algorithmic bytes -- a 4-byte x value costs a 64-byte line and hot columns are scattered over
+// lines.  Renumbering the columns by popularity packs the hot x entries into the same lines (16x the
+// effective cache capacity for them at every level): C3 2.62 -> 1.9 ms.  Built once per record at its
+// first product: column histogram -> stable sort by descending count -> rank of every entry's column
+// (col_hot).  Each product then gathers x into rank order (m elements) and runs the same kernel on
+// (col_hot, x_hot).  Entry order is untouched, so y is bit-identical to the plain path.
+// Auto mode keeps it only where it can pay: x larger than the L2s, most tiles spanning a wide column
+// range, and the columns that fit in 2 MB holding at least half of the accesses.
+constexpr int64_t kReorderMinBytes = 8 << 20;
+constexpr int64_t kReorderHotBytes = 2 << 20;
+
+__global__ __launch_bounds__(kBlock) void reorder_wide_tiles_kernel(const int32_t *__restrict__ col, int64_t nnz,
+                                                                    int64_t ntiles, int64_t tile,
+                                                                    unsigned long long *__restrict__ wide) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= ntiles) return;
+  const int64_t a = t * tile, b = (a + tile - 1 < nnz ? a + tile - 1 : nnz - 1);
+  const int64_t d = (int64_t)col[b] - (int64_t)col[a];
+  if (d > 65536 || d < -65536) atomicAdd(wide, 1ull);
+}
+
+__global__ __launch_bounds__(kBlock) void reorder_count_kernel(const int32_t *__restrict__ col, int64_t nnz,
+                                                               uint32_t *__restrict__ counts) {
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kBlock)
+    atomicAdd(&counts[col[e]], 1u);
+}
+
+// key = ~count: ascending key order = descending popularity; ties keep ascending column (stable sort)
+__global__ __launch_bounds__(kBlock) void reorder_keys_kernel(const uint32_t *__restrict__ counts, int64_t m,
+                                                              uint32_t *__restrict__ keys) {
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c < m) keys[c] = ~counts[c];
+}
+
+__global__ __launch_bounds__(kBlock) void reorder_rank_kernel(const uint32_t *__restrict__ perm,
+                                                              const uint32_t *__restrict__ sorted_keys, int64_t m,
+                                                              int64_t hot, uint32_t *__restrict__ rank_of,
+                                                              unsigned long long *__restrict__ hot_mass) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long mine = 0;
+  if (r < m) {
+    rank_of[perm[r]] = (uint32_t)r;
+    if (r < hot) mine = (unsigned long long)(~sorted_keys[r]);
+  }
+  mine = wave_reduce(mine, OpAdd());
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(hot_mass, mine);
+}
+
+__global__ __launch_bounds__(kBlock) void reorder_remap_kernel(const int32_t *__restrict__ col,
+                                                               const uint32_t *__restrict__ rank_of, int64_t nnz,
+                                                               int32_t *__restrict__ col_hot) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e < nnz) col_hot[e] = (int32_t)rank_of[col[e]];
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void reorder_gather_x_kernel(const T *__restrict__ x,
+                                                                  const uint32_t *__restrict__ perm, int64_t m,
+                                                                  T *__restrict__ x_hot) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r < m) x_hot[r] = x[perm[r]];
+}
+
+// Decides and, if worthwhile, builds the renumbering.  One-time host synchronisations (two small reads).
+template <class T>
+int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
+  a->reorder_state = -1;
+  if (ctx->opt_spmv_reorder < 0 || !a->col32 || a->nnz == 0) return 0;
+  const bool force = ctx->opt_spmv_reorder > 0;  // tests: any size
+  if ((!force && a->m * (int64_t)sizeof(T) < kReorderMinBytes) || a->m >= 0x7fffffffLL) return 0;
+  unsigned long long *stat = reinterpret_cast<unsigned long long *>(ctx->d_small);
+  int64_t host = 0;
+  if (!force) {
+    SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+    hipLaunchKernelGGL(reorder_wide_tiles_kernel, dim3((unsigned)cdiv(a->ntiles, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const int32_t *)a->col32, a->nnz, a->ntiles, a->tile, stat);
+    SAMD_LAUNCH_CHECK(ctx);
+    SAMD_TRY(read_small(ctx, ctx->d_small, 1, &host));
+    if (host * 2 < a->ntiles) return 0;  // banded / stencil-like: the gather is already local
+  }
+  Tmp<uint32_t> counts(ctx), keys_b(ctx), pay_a(ctx), pay_b(ctx);
+  SAMD_TRY(counts.get(a->m));
+  SAMD_TRY(keys_b.get(a->m));
+  SAMD_TRY(pay_a.get(a->m));
+  SAMD_TRY(pay_b.get(a->m));
+  SAMD_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(uint32_t) * (size_t)a->m, ctx->stream));
+  {
+    const int64_t want = cdiv(a->nnz, kBlock);
+    const int64_t cap = (int64_t)ctx->num_cu * 32;
+    hipLaunchKernelGGL(reorder_count_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(kBlock), 0, ctx->stream,
+                       (const int32_t *)a->col32, a->nnz, counts.p);
+    SAMD_LAUNCH_CHECK(ctx);
+  }
+  const unsigned mgrid = (unsigned)cdiv(a->m, kBlock);
+  hipLaunchKernelGGL(reorder_keys_kernel, dim3(mgrid), dim3(kBlock), 0, ctx->stream, (const uint32_t *)counts.p, a->m,
+                     counts.p);  // in place: counts now holds the keys
+  SAMD_LAUNCH_CHECK(ctx);
+  uint32_t *ks = nullptr;
+  const uint32_t *perm = nullptr;
+  SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 2, 0, sizeof(int64_t), ctx->stream));
+  SAMD_TRY((radix_sort_pairs<uint32_t, uint32_t>(ctx, counts.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
+                                                  a->m, 0, 32, &ks, &perm, (int *)(ctx->d_small + 2))));
+  // perm[rank] = column; keep it, and turn it into rank_of for the remap
+  uint32_t *hot_perm = nullptr;
+  SAMD_TRY(dalloc(ctx, &hot_perm, a->m));
+  SAMD_HIP(ctx, hipMemcpyAsync(hot_perm, perm, sizeof(uint32_t) * (size_t)a->m, hipMemcpyDeviceToDevice, ctx->stream));
+  uint32_t *rank_of = (perm == pay_a.p) ? pay_b.p : pay_a.p;  // the payload buffer the sort did not end in
+  const int64_t hot = kReorderHotBytes / (int64_t)sizeof(T) < a->m ? kReorderHotBytes / (int64_t)sizeof(T) : a->m;
+  SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+  hipLaunchKernelGGL(reorder_rank_kernel, dim3(mgrid), dim3(kBlock), 0, ctx->stream, (const uint32_t *)hot_perm,
+                     (const uint32_t *)ks, a->m, hot, rank_of, stat);
+  SAMD_LAUNCH_CHECK(ctx);
+  int64_t h2[3];
+  if (read_small(ctx, ctx->d_small, 3, h2) != 0) { dfree(ctx, hot_perm); return 1; }
+  if ((int)(h2[2] & 0xffffffff) != 0) { dfree(ctx, hot_perm); return set_error(ctx, "internal: radix sort look-back timed out"); }
+  if (!force && h2[0] * 2 < a->nnz) { dfree(ctx, hot_perm); return 0; }  // flat popularity: nothing to pack
+  int32_t *col_hot = nullptr;
+  T *x_hot = nullptr;
+  if (dalloc(ctx, &col_hot, a->nnz) != 0 || dalloc(ctx, &x_hot, a->m) != 0) {
+    dfree(ctx, hot_perm); dfree(ctx, col_hot);
+    return 1;
+  }
+  hipLaunchKernelGGL(reorder_remap_kernel, dim3((unsigned)cdiv(a->nnz, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     (const int32_t *)a->col32, (const uint32_t *)rank_of, a->nnz, col_hot);
+  SAMD_LAUNCH_CHECK(ctx);
+  a->hot_perm = hot_perm;
+  a->col_hot = col_hot;
+  a->x_hot = x_hot;
+  a->reorder_state = 1;
+  return 0;
+}
+
 template <class T, class I>
 int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T *x, T *y) {
   int64_t algo = ctx->opt_spmv_algo;
@@ -321,6 +456,14 @@ int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
   if (a->nnz == 0) {
     SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));  // empty row -> T.i64 0
     return 0;
+  }
+  const int64_t algo = ctx->opt_spmv_algo;
+  if ((algo == 0 || algo == 1) && a->reorder_state == 0) SAMD_TRY(reorder_prepare<T>(ctx, a));
+  if ((algo == 0 || algo == 1) && a->reorder_state == 1) {
+    hipLaunchKernelGGL((reorder_gather_x_kernel<T>), dim3((unsigned)cdiv(a->m, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       x, (const uint32_t *)a->hot_perm, a->m, a->x_hot);
+    SAMD_LAUNCH_CHECK(ctx);
+    return spmv_typed<T, int32_t>(ctx, a, a->col_hot, (const T *)a->x_hot, y);
   }
   if (a->col32) return spmv_typed<T, int32_t>(ctx, a, a->col32, x, y);
   return spmv_typed<T, int64_t>(ctx, a, a->col64, x, y);

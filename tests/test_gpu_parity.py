@@ -253,6 +253,30 @@ def test_smvm_rows_crossing_tile_ends(ctx, lanes):
         ctx.set_option("spmv_lanes", 0)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+def test_smvm_hot_column_renumbering_is_bit_identical(ctx, dtype):
+    """spmv_reorder=1 forces the popularity renumbering of the columns (normally kept for large power-law
+    records); entry order is untouched, so y must equal the plain path bit for bit, and the oracle."""
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    n, m = 3000, 9000
+    r, c, v = skewed_coo(n, m, dtype, 31)
+    c = (c.astype(np.float64) ** 3 / float(m) ** 2).astype(np.int64)      # pile the columns up near 0
+    x = synth.uniform_values(5, m, dtype)
+    ys = []
+    for mode in (-1, 1):
+        ctx.set_option("spmv_reorder", mode)
+        try:
+            A = M.sr.sparse(n, m, (r, c, v))
+            ys.append(M.sr.smvm(A, x).numpy())
+            ys.append(M.sr.smvm(A, x).numpy())                            # second call: cached renumbering
+            x2 = synth.uniform_values(6, m, dtype)                        # and a different x
+            close(M.sr.smvm(A, x2), O.sr_smvm(O.sr_sparse(n, m, r, c, v), x2), dtype)
+        finally:
+            ctx.set_option("spmv_reorder", 0)
+    assert all(y.tobytes() == ys[0].tobytes() for y in ys[1:])
+    close(ys[0], O.sr_smvm(O.sr_sparse(n, m, r, c, v), x), dtype)
+
+
 def test_smvm_empty_and_shape_errors(ctx):
     from sparse_amd.compressed import SparseError
     M = mk(ctx, "f64")
