@@ -1017,8 +1017,8 @@ int main(int argc, char **argv) {
 
   auto make_plan = [&](int64_t tile, int64_t **lb, double **head) {
     const int64_t nt = (nnz + tile - 1) / tile;
-    CK(hipMalloc(lb, 8 * (nt + 2)));
-    CK(hipMemsetAsync(*lb, 0, 8 * (nt + 2), st));
+    CK(hipMalloc(lb, 8 * (nt + 3)));
+    CK(hipMemsetAsync(*lb, 0, 8 * (nt + 3), st));
     CK(hipMalloc(head, 8 * nt));
     hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((nt + 1 + 255) / 256)), dim3(256), 0, st, (const int64_t *)row_ptr,
                        n, tile, nt, *lb);

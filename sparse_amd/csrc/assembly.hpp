@@ -124,25 +124,33 @@ __global__ __launch_bounds__(kBlock) void merge_emit_kernel(const K *__restrict_
 }
 
 // ---------------------------------------------------------------------- plan
-// tile_lb[ntiles + 1] (zeroed by the caller) receives the longest first spill: the largest
-// number of entries by which a row runs past the end of the tile it starts in.
+// tile_lb[ntiles + 1] and [ntiles + 2] (zeroed by the caller) receive two statistics of the plan:
+// the longest first spill (the largest number of entries by which a row runs past the end of the
+// tile it starts in) and the largest number of rows that start in one tile.
+__device__ __forceinline__ int64_t plan_lower_bound(const int64_t *__restrict__ row_ptr, int64_t n, int64_t target) {
+  int64_t lo = 0, hi = n;  // first r in [0,n) with row_ptr[r] >= target, else n
+  while (lo < hi) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (row_ptr[mid] >= target) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
 __global__ __launch_bounds__(kBlock) void plan_kernel(const int64_t *__restrict__ row_ptr, int64_t n, int64_t tile,
                                                       int64_t ntiles, int64_t *__restrict__ tile_lb) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t > ntiles) return;
   if (t == ntiles) { tile_lb[t] = n; return; }
   const int64_t target = t * tile;
-  int64_t lo = 0, hi = n;  // first r in [0,n) with row_ptr[r] >= target, else n
-  while (lo < hi) {
-    const int64_t mid = lo + (hi - lo) / 2;
-    if (row_ptr[mid] >= target) hi = mid; else lo = mid + 1;
-  }
+  const int64_t lo = plan_lower_bound(row_ptr, n, target);
   tile_lb[t] = lo;
   if (t > 0 && lo > 0) {
     const int64_t rs = row_ptr[lo - 1], re = row_ptr[lo];
     if (re > target && rs >= target - tile)  // row lo-1 starts in tile t-1 and runs into tile t
       atomicMax(reinterpret_cast<unsigned long long *>(&tile_lb[ntiles + 1]), (unsigned long long)(re - target));
   }
+  const int64_t next = t + 1 == ntiles ? n : plan_lower_bound(row_ptr, n, target + tile);
+  atomicMax(reinterpret_cast<unsigned long long *>(&tile_lb[ntiles + 2]), (unsigned long long)(next - lo));
 }
 
 constexpr int64_t kPlanTile = 1024;  // entries per tile; matches the SpMV kernels' TILE
@@ -151,10 +159,11 @@ template <class T>
 int build_plan(futhark_context *ctx, CsrBody<T> *b) {
   b->tile = kPlanTile;
   b->ntiles = cdiv(b->nnz, b->tile);
-  SAMD_TRY(dalloc(ctx, &b->tile_lb, b->ntiles + 2));
+  SAMD_TRY(dalloc(ctx, &b->tile_lb, b->ntiles + 3));
   SAMD_TRY(dalloc(ctx, &b->head, b->ntiles));
-  SAMD_HIP(ctx, hipMemsetAsync(b->tile_lb + b->ntiles + 1, 0, sizeof(int64_t), ctx->stream));
+  SAMD_HIP(ctx, hipMemsetAsync(b->tile_lb + b->ntiles + 1, 0, 2 * sizeof(int64_t), ctx->stream));
   b->spill_max = -1;
+  b->max_tile_rows = -1;
   hipLaunchKernelGGL(plan_kernel, dim3((unsigned)cdiv(b->ntiles + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                      (const int64_t *)b->row_ptr, b->n, b->tile, b->ntiles, b->tile_lb);
   SAMD_LAUNCH_CHECK(ctx);

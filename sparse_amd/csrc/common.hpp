@@ -229,7 +229,9 @@ struct CsrBody {
   int64_t *tile_lb = nullptr;
   T *head = nullptr;
   int64_t max_row_len = -1;  // filled lazily by the SpMV dispatcher
-  mutable int64_t spill_max = -1;  // longest first spill (tile_lb[ntiles+1]); read lazily, small matrices only
+  // plan statistics (tile_lb[ntiles+1], [ntiles+2]), read back once by the first product
+  mutable int64_t spill_max = -1;      // longest first spill
+  mutable int64_t max_tile_rows = -1;  // most rows starting in one tile
   // hot-column renumbering for gather-bound SpMV (spmv.hpp, "reorder"); built lazily, owned by the record
   mutable int reorder_state = 0;   // 0 undecided, 1 active, -1 rejected
   mutable int32_t *col_hot = nullptr;    // [nnz] rank of each entry's column by popularity

@@ -41,6 +41,7 @@ namespace samd {
 constexpr int kSpmvTile = (int)kPlanTile;  // entries per block
 constexpr int kSpillInline = 64;           // INLINE: a row running at most this far past its tile is finished by its owner
 constexpr int64_t kInlineMaxTiles = 4096;  // INLINE is used below this many tiles (launch-bound sizes)
+constexpr int64_t kDenseRowsMax = 2048;    // tiles in which more rows than this start take the many-empty-rows path
 
 typedef unsigned int raw16 __attribute__((ext_vector_type(4)));  // one 128-bit load/store
 
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
 
   // ---- rows of this tile: the candidate head row (lb0-1) and the rows that start here
   const int64_t rfirst = lb0 > 0 ? lb0 - 1 : 0;
-  const int nrows = (int)(lb1 - rfirst);
+  const int64_t nrows64 = lb1 - rfirst;
+  const int nrows = (int)(nrows64 <= kDenseRowsMax ? nrows64 : kDenseRowsMax + 1);
   int L = 1;  // lanes per row, from the mean fragment length (uniform over the block)
   {
     const int avg4 = cnt / (nrows > 0 ? nrows : 1) / 4;
@@ -152,6 +154,30 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
     re0 = ntload(&row_ptr[rfirst + grp + 1]);
   }
   __syncthreads();
+
+  // ---- more rows than kDenseRowsMax start in this tile: all but <= TILE of them are empty (a run of
+  // empty rows shares one row_ptr value, so whichever tile holds that position gets the whole run).
+  // The host has zero-filled y; here every entry looks up its row (binary search over the tile's rows)
+  // and the entry that opens a row fragment sums it.  Work is bounded by the tile's entries, not its rows.
+  if (nrows64 > kDenseRowsMax) {  // uniform over the block
+    for (int p = tid; p < cnt; p += kBlock) {
+      const int64_t gp = base + p;
+      int64_t lo = rfirst, hi = lb1;  // largest r in [rfirst, lb1) with row_ptr[r] <= gp
+      while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (row_ptr[mid] <= gp) lo = mid; else hi = mid;
+      }
+      const int64_t r = lo, rs = row_ptr[r];
+      if (gp != rs && p != 0) continue;  // not the first entry of its row's fragment
+      const int64_t re = row_ptr[r + 1];
+      if (INLINE && r < lb0 && re - (rs / TILE + 1) * TILE <= kSpillInline) continue;
+      const int e = (int)((re < lim2 ? re : lim2) - base);
+      const T acc = row_partial<T, I, 4>(sval, scol, x, p, e, 0, 1);
+      if (rs >= base) y[r] = acc;
+      else head[t] = acc;
+    }
+    return;
+  }
 
   // ---- phase 2: L lanes per row fragment, row-major gather of x
   for (int j = grp; j < nrows; j += ngrp) {
@@ -400,8 +426,14 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     // launch is dropped when no row spills far.  Large records keep the fix-up launch (measured faster:
     // C2 0.238 vs 0.244 ms), so nothing is read back for them.
     const bool inl = a->ntiles > 1 && a->ntiles <= kInlineMaxTiles;
-    if (inl && a->spill_max < 0)  // first product with this record: one small read, then cached
-      SAMD_TRY(read_small(ctx, a->tile_lb + a->ntiles + 1, 1, &a->spill_max));
+    if (a->max_tile_rows < 0) {  // first product with this record: one small read, then cached
+      int64_t stats[2];
+      SAMD_TRY(read_small(ctx, a->tile_lb + a->ntiles + 1, 2, stats));
+      a->spill_max = stats[0];
+      a->max_tile_rows = stats[1];
+    }
+    if (a->max_tile_rows > kDenseRowsMax)  // some tile takes the many-empty-rows path, which writes no zeros
+      SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));
     // gathers in flight per lane: what a typical row fragment needs (mean row length over the lanes it gets)
     int unroll = 8;
     {

@@ -277,6 +277,32 @@ def test_smvm_hot_column_renumbering_is_bit_identical(ctx, dtype):
     close(ys[0], O.sr_smvm(O.sr_sparse(n, m, r, c, v), x), dtype)
 
 
+@pytest.mark.parametrize("lanes", [0, 8])
+def test_smvm_long_runs_of_empty_rows(ctx, lanes):
+    """Hundreds of thousands of empty rows before, between and after the stored ones: the tile that holds a
+    run's position gets every row of it (the many-empty-rows path of spmv_stream), together with short rows,
+    a row longer than a tile and rows crossing tile ends.  i32 exact, f64 within tolerance."""
+    n, m = 700000, 5000
+    rows_with = np.concatenate([np.arange(150000, 150040), [300000], np.arange(300001, 302000, 7),
+                                [650000, 699999]]).astype(np.int64)
+    lens = np.full(len(rows_with), 5, np.int64)
+    lens[3] = 1500                       # spans two tiles
+    lens[40] = 3000                      # row 300000: longer than a tile
+    lens[-1] = 900
+    rs = np.repeat(rows_with, lens)
+    cs = np.concatenate([np.sort(synth.affine_shuffle(m, seed=int(i))[:L]) for i, L in enumerate(lens)]).astype(np.int64)
+    ctx.set_option("spmv_lanes", lanes)
+    try:
+        for dtype in ("i32", "f64"):
+            O, M = Oracle(dtype), mk(ctx, dtype)
+            v = synth.uniform_values(8, len(rs), dtype)
+            x = synth.uniform_values(9, m, dtype)
+            A = M.sr.sparse(n, m, (rs, cs, v))
+            close(M.sr.smvm(A, x), O.sr_smvm(O.sr_sparse(n, m, rs, cs, v), x), dtype)
+    finally:
+        ctx.set_option("spmv_lanes", 0)
+
+
 def test_smvm_empty_and_shape_errors(ctx):
     from sparse_amd.compressed import SparseError
     M = mk(ctx, "f64")
