@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
   __shared__ long long swin[2 * kWaves];
   __shared__ int srel[kRowCache + 1];  // row bounds relative to the tile, clamped to [-1, TILE+1]
   __shared__ int longrows[TILE / 64 + 2];
-  __shared__ int nlong;
+  __shared__ int nlong, nlist;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slot = tid >> 4, cg = tid & 15;
@@ -116,11 +116,29 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
       sval[e] = val[base + e];
     }
   }
-  if (tid == 0) nlong = 0;
+  if (tid == 0) { nlong = 0; nlist = 0; }
   const int64_t rfirst = lb0 > 0 ? lb0 - 1 : 0;
-  const int nrows = (int)(lb1 - rfirst);
+  const int64_t nrows64 = lb1 - rfirst;
+  // more rows than kDenseRowsMax start here (a run of empty rows): the host has zero-filled C and only the
+  // rows that own entries are visited; their list is built from the entries and lives in the window's LDS
+  const bool sparse_rows = nrows64 > kDenseRowsMax;  // uniform over the block
+  int nrows = sparse_rows ? 0 : (int)nrows64;
+  int64_t *rowlist = reinterpret_cast<int64_t *>(sBv);
   for (int jr = tid; jr <= nrows && jr <= kRowCache; jr += kBlock) srel[jr] = rel_clamp(row_ptr[rfirst + jr], base, TILE);
   __syncthreads();
+  if (sparse_rows) {
+    for (int p = tid; p < cnt; p += kBlock) {
+      const int64_t gp = base + p;
+      int64_t lo = rfirst, hi = lb1;  // largest r in [rfirst, lb1) with row_ptr[r] <= gp
+      while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (row_ptr[mid] <= gp) lo = mid; else hi = mid;
+      }
+      if (gp == row_ptr[lo] || p == 0) rowlist[atomicAdd(&nlist, 1)] = lo;
+    }
+    __syncthreads();
+    nrows = nlist;
+  }
 
   // column window of the tile
   long long cmin = 0x7fffffffffffffffLL, cmax = -1;
@@ -142,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
     cmin = swin[w] < cmin ? swin[w] : cmin;
     cmax = swin[kWaves + w] > cmax ? swin[kWaves + w] : cmax;
   }
-  const int wrows = (int)(cmax - cmin + 1 <= kWinRows ? cmax - cmin + 1 : 0);  // 0: no window
+  const int wrows = (int)(!sparse_rows && cmax - cmin + 1 <= kWinRows ? cmax - cmin + 1 : 0);  // 0: no window
 
   constexpr int P = 16 / (int)sizeof(T);  // elements per 16-byte piece
   constexpr int P16 = P;
@@ -237,9 +255,9 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
     }
     // ---- one slot (16 lanes x 4 columns) per row fragment, adjacent rows on the 16 slots
     for (int jr = slot; jr < nrows; jr += 16) {
-      const int64_t r = rfirst + jr;
+      const int64_t r = sparse_rows ? rowlist[jr] : rfirst + jr;
       int rs, re;  // relative to the tile
-      if (jr < kRowCache) { rs = srel[jr]; re = srel[jr + 1]; }
+      if (!sparse_rows && jr < kRowCache) { rs = srel[jr]; re = srel[jr + 1]; }
       else { rs = rel_clamp(row_ptr[r], base, TILE); re = rel_clamp(row_ptr[r + 1], base, TILE); }
       if (r < lb0 && re <= 0) continue;
       const int s = rs > 0 ? rs : 0;
@@ -275,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
     // ---- long fragments: the 16 slots split the entries; partial strips meet via shuffles + LDS
     const int nl = nlong;
     for (int i = 0; i < nl; i++) {
-      const int64_t r = rfirst + longrows[i];
+      const int64_t r = sparse_rows ? rowlist[longrows[i]] : rfirst + longrows[i];
       const int rs = rel_clamp(row_ptr[r], base, TILE), re = rel_clamp(row_ptr[r + 1], base, TILE);
       const int s = rs > 0 ? rs : 0;
       const int e = re < cnt ? re : cnt;
@@ -349,6 +367,9 @@ int spmm_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
   if (a->tile != kSpmvTile) return set_error(ctx, "spmm: plan tile mismatch");
   Tmp<T> head(ctx);
   SAMD_TRY(head.get(a->ntiles * k));
+  SAMD_TRY(plan_stats(ctx, a));
+  if (a->max_tile_rows > kDenseRowsMax)  // some tile visits only the rows that own entries: the rest must be zero
+    SAMD_HIP(ctx, hipMemsetAsync(C, 0, sizeof(T) * (size_t)(a->n * k), ctx->stream));
   // 16-byte accesses need every row of B, C and of the head rows 16-byte aligned
   const bool vec = ((k * sizeof(T)) % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0);
   if (vec)

@@ -414,6 +414,17 @@ int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
   return 0;
 }
 
+// the plan's two statistics: read back by the first product with a record, then cached
+template <class T>
+int plan_stats(futhark_context *ctx, const CsrBody<T> *a) {
+  if (a->max_tile_rows >= 0) return 0;
+  int64_t stats[2];
+  SAMD_TRY(read_small(ctx, a->tile_lb + a->ntiles + 1, 2, stats));
+  a->spill_max = stats[0];
+  a->max_tile_rows = stats[1];
+  return 0;
+}
+
 template <class T, class I>
 int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T *x, T *y) {
   int64_t algo = ctx->opt_spmv_algo;
@@ -426,12 +437,7 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     // launch is dropped when no row spills far.  Large records keep the fix-up launch (measured faster:
     // C2 0.238 vs 0.244 ms), so nothing is read back for them.
     const bool inl = a->ntiles > 1 && a->ntiles <= kInlineMaxTiles;
-    if (a->max_tile_rows < 0) {  // first product with this record: one small read, then cached
-      int64_t stats[2];
-      SAMD_TRY(read_small(ctx, a->tile_lb + a->ntiles + 1, 2, stats));
-      a->spill_max = stats[0];
-      a->max_tile_rows = stats[1];
-    }
+    SAMD_TRY(plan_stats(ctx, a));
     if (a->max_tile_rows > kDenseRowsMax)  // some tile takes the many-empty-rows path, which writes no zeros
       SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));
     // gathers in flight per lane: what a typical row fragment needs (mean row length over the lanes it gets)

@@ -298,7 +298,11 @@ def test_smvm_long_runs_of_empty_rows(ctx, lanes):
             v = synth.uniform_values(8, len(rs), dtype)
             x = synth.uniform_values(9, m, dtype)
             A = M.sr.sparse(n, m, (rs, cs, v))
-            close(M.sr.smvm(A, x), O.sr_smvm(O.sr_sparse(n, m, rs, cs, v), x), dtype)
+            Ao = O.sr_sparse(n, m, rs, cs, v)
+            close(M.sr.smvm(A, x), O.sr_smvm(Ao, x), dtype)
+            if lanes == 0:                                   # the same record through the panel product
+                B = synth.uniform_values(10, m * 8, dtype).reshape(m, 8)
+                close(M.sr.smm(A, B), O.sr_smm(Ao, B), dtype)
     finally:
         ctx.set_option("spmv_lanes", 0)
 
