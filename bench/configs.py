@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--algo", type=int, default=0)
+    ap.add_argument("--spmm-algo", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--compare", action="store_true", help="also time torch.sparse (rocSPARSE) CSR SpMV as a comparator")
@@ -45,6 +46,8 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.algo:
         ctx.set_option("spmv_algo", args.algo)
+    if args.spmm_algo:
+        ctx.set_option("spmm_algo", args.spmm_algo)
     if args.lanes:
         ctx.set_option("spmv_lanes", args.lanes)
     if args.ablate:

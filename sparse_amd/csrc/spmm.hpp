@@ -65,7 +65,45 @@ __global__ __launch_bounds__(kBlock) void spmm_rowpanel_kernel(const int64_t *__
 //     adds + LDS;
 //   * rows crossing tiles: owner tile stores, later tiles store a k-wide head row, the
 //     fix-up kernel adds them in tile order (no atomics).
+//   * dense block on the matrix cores: when the tile is banded (column window <= kWinRows) and its rows
+//     are long (mean fragment >= kMfmaMinLen entries, at most 64 rows), the rows are laid out as
+//     up to four dense 16 x window blocks in LDS (zero-filled) and each wavefront multiplies them with its
+//     16 columns of the strip's B window by v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32: one B fragment
+//     (read once from global memory into registers) serves all row groups, and a 16-row group costs
+//     2 LDS reads per MFMA instead of 2 per entry and 16 lanes.  A window slice that holds a non-finite
+//     B value is multiplied entry by entry instead (0 * inf of the zero fill must not reach C).
 constexpr int kWinRows = 72;    // rows of B (x 64 columns) staged per tile
+constexpr int kMfmaMinLen = 16; // mean row-fragment length from which a banded tile goes to the matrix cores
+constexpr int kMfmaSteps = kWinRows / 4;
+
+template <class T>
+struct Mfma { static constexpr bool ok = false; };
+template <>
+struct Mfma<double> {
+  static constexpr bool ok = true;
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // result register i of lane l holds row (l >> 4) + 4 i, column l & 15
+  static __device__ __forceinline__ int row(int lane, int i) { return (lane >> 4) + 4 * i; }
+  static __device__ __forceinline__ bool nonfinite(double v) {
+    return (__double_as_longlong(v) & 0x7ff0000000000000LL) == 0x7ff0000000000000LL;
+  }
+};
+template <>
+struct Mfma<float> {
+  static constexpr bool ok = true;
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // result register i of lane l holds row 4 (l >> 4) + i, column l & 15
+  static __device__ __forceinline__ int row(int lane, int i) { return (lane >> 4) * 4 + i; }
+  static __device__ __forceinline__ bool nonfinite(float v) {
+    return (__float_as_int(v) & 0x7f800000) == 0x7f800000;
+  }
+};
 constexpr int kRowCache = 256;  // row bounds of the tile's first rows, read once into LDS
 
 __device__ __forceinline__ int rel_clamp(int64_t v, int64_t base, int tile) {
@@ -79,7 +117,9 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
                                                              const T *__restrict__ B, T *__restrict__ C,
                                                              const int64_t *__restrict__ tile_lb,
                                                              T *__restrict__ head, int64_t nnz, int64_t ntiles,
-                                                             int64_t k, int ablate) {
+                                                             int64_t k, int ablate,
+                                                             const uint8_t *__restrict__ tile_class) {
+  if (tile_class && tile_class[xcd_remap(blockIdx.x, ntiles)]) return;  // a dense-block tile: spmm_mfma_kernel's
   __shared__ __attribute__((aligned(16))) T sval[TILE];
   __shared__ __attribute__((aligned(16))) I scol[TILE];
   __shared__ raw16 sBv[kWinRows * 64 * sizeof(T) / 16];  // B window, addressed in 16-byte units
@@ -331,6 +371,211 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
   }
 }
 
+// ---- dense-block tiles on the matrix cores
+// Which tiles qualify is a property of the record: decided once (first product), one byte per tile.
+template <class I, int TILE>
+__global__ __launch_bounds__(64) void spmm_classify_kernel(const I *__restrict__ col,
+                                                           const int64_t *__restrict__ tile_lb, int64_t nnz,
+                                                           int64_t ntiles, uint8_t *__restrict__ tile_class,
+                                                           unsigned long long *__restrict__ count) {
+  const int64_t t = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t base = t * TILE;
+  const int cnt = (int)((nnz - base) < (int64_t)TILE ? (nnz - base) : (int64_t)TILE);
+  const int64_t lb0 = tile_lb[t], lb1 = tile_lb[t + 1];
+  const int64_t rfirst = lb0 > 0 ? lb0 - 1 : 0;
+  const int64_t nrows = lb1 - rfirst;
+  bool ok = nrows > 0 && nrows <= 64 && (int64_t)cnt >= kMfmaMinLen * nrows;  // uniform
+  if (ok) {
+    long long cmin = 0x7fffffffffffffffLL, cmax = -1;
+    for (int e = lane; e < cnt; e += 64) {
+      const long long c = (long long)col[base + e];
+      cmin = c < cmin ? c : cmin;
+      cmax = c > cmax ? c : cmax;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const long long a = wshfl_xor(cmin, d), b = wshfl_xor(cmax, d);
+      cmin = a < cmin ? a : cmin;
+      cmax = b > cmax ? b : cmax;
+    }
+    ok = cmax - cmin + 1 <= kWinRows;
+  }
+  if (lane == 0) {
+    tile_class[t] = ok ? 1 : 0;
+    if (ok) atomicAdd(count, 1ULL);
+  }
+}
+
+// One block per qualifying tile.  The tile's rows (at most 64) become up to four dense
+// [window column][16 rows] blocks in LDS; wavefront w owns columns 16w..16w+15 of every 64-wide strip
+// of C: its B fragments of the whole window come straight from global memory into registers (128-byte row
+// pieces, all loads in flight while the dense blocks are built) and serve every row group; A fragments
+// come from LDS (64 consecutive elements per read: conflict-free).
+
+template <class T, class I, int TILE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void spmm_mfma_kernel(const int64_t *__restrict__ row_ptr,
+                                                           const I *__restrict__ col, const T *__restrict__ val,
+                                                           const T *__restrict__ B, T *__restrict__ C,
+                                                           const int64_t *__restrict__ tile_lb,
+                                                           T *__restrict__ head,
+                                                           const uint8_t *__restrict__ tile_class, int64_t nnz,
+                                                           int64_t ntiles, int64_t k, int64_t m) {
+  typedef typename Mfma<T>::acc_t acc_t;
+  const int64_t t = xcd_remap(blockIdx.x, ntiles);
+  if (!tile_class[t]) return;
+  __shared__ __attribute__((aligned(16))) T sval[TILE];
+  __shared__ __attribute__((aligned(16))) I scol[TILE];
+  __shared__ raw16 sAv[4 * kWinRows * 16 * sizeof(T) / 16];
+  __shared__ int srel[66];
+  T *Ad = reinterpret_cast<T *>(sAv);  // [group][window column][16 rows]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = tid >> 4, cg = tid & 15;
+  const int64_t base = t * TILE;
+  const int cnt = (int)((nnz - base) < (int64_t)TILE ? (nnz - base) : (int64_t)TILE);
+  const int64_t lb0 = tile_lb[t], lb1 = tile_lb[t + 1];
+  const int64_t rfirst = lb0 > 0 ? lb0 - 1 : 0;
+  const int nrows = (int)(lb1 - rfirst);  // 1..64 (classified)
+  const int ngroups = (nrows + 15) >> 4;
+  constexpr int CV = TILE * (int)sizeof(I) / (16 * kBlock);
+  constexpr int VV = TILE * (int)sizeof(T) / (16 * kBlock);
+  if (cnt == TILE) {
+    raw16 c[CV], a[VV];
+    const raw16 *cp = reinterpret_cast<const raw16 *>(col + base);
+    const raw16 *vp = reinterpret_cast<const raw16 *>(val + base);
+#pragma unroll
+    for (int it = 0; it < CV; it++) c[it] = ntload(cp + it * kBlock + tid);
+#pragma unroll
+    for (int it = 0; it < VV; it++) a[it] = ntload(vp + it * kBlock + tid);
+#pragma unroll
+    for (int it = 0; it < CV; it++) reinterpret_cast<raw16 *>(scol)[it * kBlock + tid] = c[it];
+#pragma unroll
+    for (int it = 0; it < VV; it++) reinterpret_cast<raw16 *>(sval)[it * kBlock + tid] = a[it];
+  } else {
+    for (int e = tid; e < cnt; e += kBlock) {
+      scol[e] = col[base + e];
+      sval[e] = val[base + e];
+    }
+  }
+  for (int jr = tid; jr <= nrows; jr += kBlock) srel[jr] = rel_clamp(row_ptr[rfirst + jr], base, TILE);
+  const int zpieces = ngroups * kWinRows * 16 * (int)sizeof(T) / 16;
+  for (int p = tid; p < zpieces; p += kBlock) sAv[p] = raw16{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  // Every wavefront works out the window by itself (lane = row): columns ascend within a row, so the
+  // first / last entry of each row fragment bound its group's columns and the tile's window.
+  long long c0 = 0x7fffffffffffffffLL, c1 = -1;
+  if (lane < nrows) {
+    const int rs = srel[lane], re = srel[lane + 1];
+    const int s = rs > 0 ? rs : 0;
+    const int e = re < cnt ? re : cnt;
+    if (e > s) { c0 = (long long)scol[s]; c1 = (long long)scol[e - 1]; }
+  }
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) {
+    const long long a = wshfl_xor(c0, d), b = wshfl_xor(c1, d);
+    c0 = a < c0 ? a : c0;
+    c1 = b > c1 ? b : c1;
+  }
+  long long cmin = c0;
+#pragma unroll
+  for (int d = 32; d >= 16; d >>= 1) {
+    const long long a = wshfl_xor(cmin, d);
+    cmin = a < cmin ? a : cmin;
+  }
+  // A group's entries lie in MFMA steps klo..khi of the window (4 columns each); the window's 18 steps are
+  // walked in thirds and a group skips the thirds it has nothing in (the rest of a third is zero fill).
+  int klo[4], khi[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const long long lo = __shfl(c0, g * 16, 64), hi = __shfl(c1, g * 16, 64);
+    klo[g] = hi < 0 ? kMfmaSteps : (int)((lo - cmin) >> 2);
+    khi[g] = hi < 0 ? -1 : (int)((hi - cmin) >> 2);
+  }
+
+  const int kq = lane >> 4, jc = lane & 15;
+  // B fragments of the window for this wavefront's 16 columns: rows cmin + 4 kk + kq, column j.  Rows past
+  // the matrix and columns past k are clamped to valid addresses: their products meet the zero fill / are
+  // never stored.
+  T b[kMfmaSteps];
+  auto load_b = [&](int64_t j) {
+    const int64_t jj = j < k ? j : k - 1;
+#pragma unroll
+    for (int kk = 0; kk < kMfmaSteps; kk++) {
+      int64_t row = cmin + kk * 4 + kq;
+      row = row < m ? row : m - 1;
+      b[kk] = B[row * k + jj];
+    }
+  };
+  const int64_t cb0 = 16 * wave;
+  if (cb0 < k) load_b(cb0 + jc);  // first strip: the loads fly while the dense blocks are built
+
+  for (int jr = slot; jr < nrows; jr += 16) {
+    const int rs = srel[jr], re = srel[jr + 1];
+    const int s = rs > 0 ? rs : 0;
+    const int e = re < cnt ? re : cnt;
+    const int g = jr >> 4, rr = jr & 15;
+    for (int q = s + cg; q < e; q += 16) Ad[(g * kWinRows + (int)((long long)scol[q] - cmin)) * 16 + rr] = sval[q];
+  }
+  __syncthreads();
+
+  constexpr int kThird = kMfmaSteps / 3;
+  for (int64_t cb = cb0; cb < k; cb += 64) {
+    const int64_t j = cb + jc;
+    const bool jl = j < k;
+    if (cb != cb0) load_b(j);
+    bool bad = false;
+#pragma unroll
+    for (int kk = 0; kk < kMfmaSteps; kk++) bad = bad || Mfma<T>::nonfinite(b[kk]);
+    const bool nf = __any(bad);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (g >= ngroups) continue;
+      if (nf) {
+        // a non-finite value of B in the window: 0 * inf of the zero fill must not reach C, so these
+        // 16 rows x 16 columns are multiplied entry by entry
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int jr = g * 16 + kq + 4 * i;
+          if (jr >= nrows || !jl) continue;
+          const int rs = srel[jr], re = srel[jr + 1];
+          const int64_t r = rfirst + jr;
+          if (r < lb0 && re <= 0) continue;
+          const int s = rs > 0 ? rs : 0;
+          const int e = re < cnt ? re : cnt;
+          T sum = (T)0;
+          for (int q = s; q < e; q++) sum = (T)(sum + (T)(sval[q] * B[(int64_t)scol[q] * k + j]));
+          (rs >= 0 ? C + r * k : head + t * k)[j] = sum;
+        }
+        continue;
+      }
+      acc_t acc = acc_t{(T)0, (T)0, (T)0, (T)0};
+#pragma unroll
+      for (int h = 0; h < 3; h++) {
+        if (klo[g] < (h + 1) * kThird && khi[g] >= h * kThird) {  // uniform
+          T a[kThird];
+#pragma unroll
+          for (int i = 0; i < kThird; i++) a[i] = Ad[(g * kWinRows + (h * kThird + i) * 4 + kq) * 16 + jc];
+#pragma unroll
+          for (int i = 0; i < kThird; i++) acc = Mfma<T>::mma(a[i], b[h * kThird + i], acc);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int jr = g * 16 + Mfma<T>::row(lane, i);
+        if (jr < nrows && jl) {
+          const int rs = srel[jr], re = srel[jr + 1];
+          const int64_t r = rfirst + jr;
+          if (r < lb0 && re <= 0) continue;
+          if (rs >= 0) __builtin_nontemporal_store(acc[i], C + r * k + j);
+          else head[t * k + j] = acc[i];
+        }
+      }
+    }
+  }
+}
+
 // one block per tile t >= 1: if t is the first spill of its head row, fold the k-wide heads
 template <class T, int TILE>
 __global__ __launch_bounds__(64) void spmm_fixup_kernel(const int64_t *__restrict__ row_ptr,
@@ -372,14 +617,40 @@ int spmm_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     SAMD_HIP(ctx, hipMemsetAsync(C, 0, sizeof(T) * (size_t)(a->n * k), ctx->stream));
   // 16-byte accesses need every row of B, C and of the head rows 16-byte aligned
   const bool vec = ((k * sizeof(T)) % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0);
-  if (vec)
+  const int flags = (int)ctx->opt_ablate;
+  const uint8_t *cls = nullptr;
+  if constexpr (Mfma<T>::ok) {
+    if (ctx->opt_spmm_algo != 3) {  // spmm_algo 3: never the matrix cores
+      if (a->n_mfma_tiles < 0) {
+        SAMD_TRY(dalloc(ctx, &a->tile_class, a->ntiles));
+        SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+        hipLaunchKernelGGL((spmm_classify_kernel<I, kSpmvTile>), dim3((unsigned)a->ntiles), dim3(64), 0, ctx->stream, col,
+                           (const int64_t *)a->tile_lb, a->nnz, a->ntiles, a->tile_class,
+                           reinterpret_cast<unsigned long long *>(ctx->d_small));
+        SAMD_LAUNCH_CHECK(ctx);
+        int64_t cnt = 0;
+        SAMD_TRY(read_small(ctx, ctx->d_small, 1, &cnt));
+        a->n_mfma_tiles = cnt;
+      }
+      if (a->n_mfma_tiles > 0) {
+        cls = a->tile_class;
+        hipLaunchKernelGGL((spmm_mfma_kernel<T, I, kSpmvTile>), dim3((unsigned)a->ntiles), dim3(kBlock), 0, ctx->stream,
+                           (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C, (const int64_t *)a->tile_lb,
+                           head.p, cls, a->nnz, a->ntiles, k, a->m);
+        SAMD_LAUNCH_CHECK(ctx);
+      }
+    }
+  }
+  const bool all_mfma = cls && a->n_mfma_tiles == a->ntiles;
+  if (all_mfma) {
+  } else if (vec)
     hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, true>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
                        ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C,
-                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, (int)ctx->opt_ablate);
+                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, flags, cls);
   else
     hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, false>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
                        ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C,
-                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, (int)ctx->opt_ablate);
+                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, flags, cls);
   SAMD_LAUNCH_CHECK(ctx);
   if (a->ntiles > 1) {
     hipLaunchKernelGGL((spmm_fixup_kernel<T, kSpmvTile>), dim3((unsigned)(a->ntiles - 1)), dim3(64), 0, ctx->stream,

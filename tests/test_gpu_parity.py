@@ -390,6 +390,67 @@ def test_smm_matches_oracle(ctx, dtype, k, algo):
         ctx.set_option("spmm_algo", 0)
 
 
+def _banded_with_holes(n, hb, dtype, seed):
+    """Band of half-width hb with some rows emptied, some thinned and one row much longer than a tile."""
+    r, c, v = synth.banded_coo(n, hb, dtype)
+    keep = np.ones(len(r), bool)
+    keep[(r % 97 == 5) | ((r >= 700) & (r < 760))] = False           # empty rows, and a run of them
+    keep[(r % 11 == 3) & (c % 2 == 0)] = False                         # thinned rows
+    extra_c = np.arange(0, min(n, 2600), dtype=np.int64)               # one row spanning several tiles
+    extra_r = np.full(len(extra_c), 1234 if n > 1234 else 0, np.int64)
+    r = np.concatenate([r[keep], extra_r])
+    c = np.concatenate([c[keep], extra_c])
+    v = synth.uniform_values(seed, len(r), dtype)
+    return r, c, v
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("k", [64, 16, 40, 130])
+def test_smm_matrix_core_tiles(ctx, dtype, k):
+    """Banded tiles with long rows take the dense-block (MFMA) path of spmm_stream; the same record with
+    spmm_algo 3 never does.  Both against the oracle, on a band with empty rows, thinned rows, rows crossing
+    tile ends and a row longer than a tile (whose tiles cannot use the dense block)."""
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    for n, hb in ((5000, 13), (3000, 30), (777, 9)):
+        r, c, v = _banded_with_holes(n, hb, dtype, seed=70 + hb)
+        A, Ao = M.sr.sparse(n, n, (r, c, v)), O.sr_sparse(n, n, r, c, v)
+        B = synth.uniform_values(71, n * k, dtype).reshape(n, k)
+        want = O.sr_smm(Ao, B)
+        got = M.sr.smm(A, B).numpy()
+        close(got, want, dtype)
+        assert got.tobytes() == M.sr.smm(A, B).numpy().tobytes()      # reproducible
+        ctx.set_option("spmm_algo", 3)
+        try:
+            close(M.sr.smm(A, B), want, dtype)
+        finally:
+            ctx.set_option("spmm_algo", 0)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_smm_matrix_core_tiles_keep_nonfinite_rows_of_B_local(ctx, dtype):
+    """The dense block is zero-filled; 0 * inf must not leak into rows that do not reference the row of B
+    holding the inf / nan: same pattern of non-finite results as the oracle, finite values within tolerance."""
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    n, hb, k = 4000, 13, 64
+    r, c, v = synth.banded_coo(n, hb, dtype)
+    keep = ~((c == 1000) & (r != 1003)) & ~((c == 2500) & (r % 2 == 0))   # column 1000 referenced by one row only
+    r, c, v = r[keep], c[keep], v[keep]
+    A, Ao = M.sr.sparse(n, n, (r, c, v)), O.sr_sparse(n, n, r, c, v)
+    B = synth.uniform_values(72, n * k, dtype).reshape(n, k).copy()
+    B[1000, :] = np.inf
+    B[2500, 7] = np.nan
+    B[2500, 40] = -np.inf
+    with np.errstate(invalid="ignore"):
+        want = O.sr_smm(Ao, B)
+    got = M.sr.smm(A, B).numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    fin = np.isfinite(want)
+    assert fin.sum() > 0.9 * fin.size and (~fin).sum() > 0
+    np.testing.assert_allclose(got[fin], want[fin], rtol=RTOL[dtype], atol=0)
+    assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)])
+
+
 @pytest.mark.parametrize("dtype", ["f64", "i32"])
 def test_smsmm_matches_oracle(ctx, dtype):
     Oc, M = OracleCompressed(dtype), mk(ctx, dtype)
