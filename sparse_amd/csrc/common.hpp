@@ -238,7 +238,7 @@ struct CsrBody {
   mutable uint32_t *hot_perm = nullptr;  // [m]   hot_perm[rank] = column
   mutable T *x_hot = nullptr;            // [m]   x gathered into rank order, rewritten by every product
   // SpMM: tiles that go to the matrix cores (spmm.hpp), decided at the first product
-  mutable uint8_t *tile_class = nullptr;  // [ntiles] 1 = dense-block tile
+  mutable int32_t *tile_split = nullptr;  // [ntiles] ids of the dense-block tiles, then of the others
   mutable int64_t n_mfma_tiles = -1;
   int refs = 1;
 };
@@ -256,7 +256,7 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->col_hot);
   dfree(ctx, b->hot_perm);
   dfree(ctx, b->x_hot);
-  dfree(ctx, b->tile_class);
+  dfree(ctx, b->tile_split);
   delete b;
 }
 

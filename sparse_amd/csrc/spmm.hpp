@@ -12,6 +12,9 @@
 // (~2.4 flop/B at k=64, below the f64 ridge).
 #pragma once
 
+#include <type_traits>
+#include <vector>
+
 #include "spmv.hpp"
 
 namespace samd {
@@ -118,8 +121,7 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
                                                              const int64_t *__restrict__ tile_lb,
                                                              T *__restrict__ head, int64_t nnz, int64_t ntiles,
                                                              int64_t k, int ablate,
-                                                             const uint8_t *__restrict__ tile_class) {
-  if (tile_class && tile_class[xcd_remap(blockIdx.x, ntiles)]) return;  // a dense-block tile: spmm_mfma_kernel's
+                                                             const int32_t *__restrict__ tile_list, int64_t ntlist) {
   __shared__ __attribute__((aligned(16))) T sval[TILE];
   __shared__ __attribute__((aligned(16))) I scol[TILE];
   __shared__ raw16 sBv[kWinRows * 64 * sizeof(T) / 16];  // B window, addressed in 16-byte units
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(kBlock) void spmm_stream_kernel(const int64_t *__re
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slot = tid >> 4, cg = tid & 15;
-  const int64_t t = xcd_remap(blockIdx.x, ntiles);
+  // tile_list: the tiles that are not spmm_mfma_kernel's (null: all tiles)
+  const int64_t t = tile_list ? (int64_t)tile_list[xcd_remap(blockIdx.x, ntlist)] : xcd_remap(blockIdx.x, ntiles);
   const int64_t base = t * TILE;
   const int cnt = (int)((nnz - base) < (int64_t)TILE ? (nnz - base) : (int64_t)TILE);
   const int64_t lb0 = tile_lb[t], lb1 = tile_lb[t + 1];
@@ -407,134 +410,166 @@ __global__ __launch_bounds__(64) void spmm_classify_kernel(const I *__restrict__
   }
 }
 
-// One block per qualifying tile.  The tile's rows (at most 64) become up to four dense
-// [window column][16 rows] blocks in LDS; wavefront w owns columns 16w..16w+15 of every 64-wide strip
-// of C: its B fragments of the whole window come straight from global memory into registers (128-byte row
-// pieces, all loads in flight while the dense blocks are built) and serve every row group; A fragments
-// come from LDS (64 consecutive elements per read: conflict-free).
-
+// One block per qualifying tile (tile_list).  The tile's rows (at most 64) are taken 16 at a time: a group
+// becomes a dense [window column][16 rows] block in LDS (two buffers: group g+1 is laid out while group g
+// is multiplied; a buffer is cleaned by writing zeros over exactly the entries it held, by the same
+// 16 lanes that wrote them).  Wavefront w owns columns 16w..16w+15 of every 64-wide strip of C: its
+// B fragments of the whole window come straight from global memory into registers (128-byte row pieces,
+// all loads in flight while the first block is built) and serve every row group; A fragments come from
+// LDS (64 consecutive elements per read: conflict-free).
 template <class T, class I, int TILE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void spmm_mfma_kernel(const int64_t *__restrict__ row_ptr,
-                                                           const I *__restrict__ col, const T *__restrict__ val,
-                                                           const T *__restrict__ B, T *__restrict__ C,
-                                                           const int64_t *__restrict__ tile_lb,
-                                                           T *__restrict__ head,
-                                                           const uint8_t *__restrict__ tile_class, int64_t nnz,
-                                                           int64_t ntiles, int64_t k, int64_t m) {
+__global__ __launch_bounds__(kBlock) void spmm_mfma_kernel(
+    const int64_t *__restrict__ row_ptr, const I *__restrict__ col, const T *__restrict__ val,
+    const T *__restrict__ B, T *__restrict__ C, const int64_t *__restrict__ tile_lb, T *__restrict__ head,
+    const int32_t *__restrict__ tile_list, int64_t nlist, int64_t nnz, int64_t k, int64_t m) {
   typedef typename Mfma<T>::acc_t acc_t;
-  const int64_t t = xcd_remap(blockIdx.x, ntiles);
-  if (!tile_class[t]) return;
   __shared__ __attribute__((aligned(16))) T sval[TILE];
   __shared__ __attribute__((aligned(16))) I scol[TILE];
-  __shared__ raw16 sAv[4 * kWinRows * 16 * sizeof(T) / 16];
+  __shared__ raw16 sAv[2 * kWinRows * 16 * sizeof(T) / 16];
   __shared__ int srel[66];
-  T *Ad = reinterpret_cast<T *>(sAv);  // [group][window column][16 rows]
+  T *Ad = reinterpret_cast<T *>(sAv);  // [buffer][window column][16 rows]
+  constexpr int kBuf = kWinRows * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slot = tid >> 4, cg = tid & 15;
+  const int64_t t = (int64_t)tile_list[xcd_remap(blockIdx.x, nlist)];
   const int64_t base = t * TILE;
   const int cnt = (int)((nnz - base) < (int64_t)TILE ? (nnz - base) : (int64_t)TILE);
+  constexpr int CV = TILE * (int)sizeof(I) / (16 * kBlock);
+  constexpr int VV = TILE * (int)sizeof(T) / (16 * kBlock);
+  raw16 ec[CV], ea[VV];
+  if (cnt == TILE) {  // the entries are requested first: nothing below is needed to address them
+    const raw16 *cp = reinterpret_cast<const raw16 *>(col + base);
+    const raw16 *vp = reinterpret_cast<const raw16 *>(val + base);
+#pragma unroll
+    for (int it = 0; it < CV; it++) ec[it] = ntload(cp + it * kBlock + tid);
+#pragma unroll
+    for (int it = 0; it < VV; it++) ea[it] = ntload(vp + it * kBlock + tid);
+  }
   const int64_t lb0 = tile_lb[t], lb1 = tile_lb[t + 1];
   const int64_t rfirst = lb0 > 0 ? lb0 - 1 : 0;
   const int nrows = (int)(lb1 - rfirst);  // 1..64 (classified)
   const int ngroups = (nrows + 15) >> 4;
-  constexpr int CV = TILE * (int)sizeof(I) / (16 * kBlock);
-  constexpr int VV = TILE * (int)sizeof(T) / (16 * kBlock);
+  for (int jr = tid; jr <= nrows; jr += kBlock) srel[jr] = rel_clamp(row_ptr[rfirst + jr], base, TILE);
+  constexpr int kZ = 2 * kBuf * (int)sizeof(T) / 16;
+  for (int p = tid; p < kZ; p += kBlock) sAv[p] = raw16{0u, 0u, 0u, 0u};
   if (cnt == TILE) {
-    raw16 c[CV], a[VV];
-    const raw16 *cp = reinterpret_cast<const raw16 *>(col + base);
-    const raw16 *vp = reinterpret_cast<const raw16 *>(val + base);
 #pragma unroll
-    for (int it = 0; it < CV; it++) c[it] = ntload(cp + it * kBlock + tid);
+    for (int it = 0; it < CV; it++) reinterpret_cast<raw16 *>(scol)[it * kBlock + tid] = ec[it];
 #pragma unroll
-    for (int it = 0; it < VV; it++) a[it] = ntload(vp + it * kBlock + tid);
-#pragma unroll
-    for (int it = 0; it < CV; it++) reinterpret_cast<raw16 *>(scol)[it * kBlock + tid] = c[it];
-#pragma unroll
-    for (int it = 0; it < VV; it++) reinterpret_cast<raw16 *>(sval)[it * kBlock + tid] = a[it];
+    for (int it = 0; it < VV; it++) reinterpret_cast<raw16 *>(sval)[it * kBlock + tid] = ea[it];
   } else {
     for (int e = tid; e < cnt; e += kBlock) {
       scol[e] = col[base + e];
       sval[e] = val[base + e];
     }
   }
-  for (int jr = tid; jr <= nrows; jr += kBlock) srel[jr] = rel_clamp(row_ptr[rfirst + jr], base, TILE);
-  const int zpieces = ngroups * kWinRows * 16 * (int)sizeof(T) / 16;
-  for (int p = tid; p < zpieces; p += kBlock) sAv[p] = raw16{0u, 0u, 0u, 0u};
   __syncthreads();
 
   // Every wavefront works out the window by itself (lane = row): columns ascend within a row, so the
   // first / last entry of each row fragment bound its group's columns and the tile's window.
-  long long c0 = 0x7fffffffffffffffLL, c1 = -1;
+  typedef typename std::conditional<sizeof(I) == 4, int, long long>::type cw_t;  // a column, as wide as stored
+  constexpr cw_t kNone = sizeof(I) == 4 ? (cw_t)0x7fffffff : (cw_t)0x7fffffffffffffffLL;
+  cw_t c0 = kNone, c1 = -1;
   if (lane < nrows) {
     const int rs = srel[lane], re = srel[lane + 1];
     const int s = rs > 0 ? rs : 0;
     const int e = re < cnt ? re : cnt;
-    if (e > s) { c0 = (long long)scol[s]; c1 = (long long)scol[e - 1]; }
+    if (e > s) { c0 = (cw_t)scol[s]; c1 = (cw_t)scol[e - 1]; }
   }
 #pragma unroll
   for (int d = 8; d >= 1; d >>= 1) {
-    const long long a = wshfl_xor(c0, d), b = wshfl_xor(c1, d);
+    const cw_t a = wshfl_xor(c0, d), b = wshfl_xor(c1, d);
     c0 = a < c0 ? a : c0;
     c1 = b > c1 ? b : c1;
   }
-  long long cmin = c0;
+  cw_t cmin_v = c0;
 #pragma unroll
   for (int d = 32; d >= 16; d >>= 1) {
-    const long long a = wshfl_xor(cmin, d);
-    cmin = a < cmin ? a : cmin;
+    const cw_t a = wshfl_xor(cmin_v, d);
+    cmin_v = a < cmin_v ? a : cmin_v;
   }
-  // A group's entries lie in MFMA steps klo..khi of the window (4 columns each); the window's 18 steps are
-  // walked in thirds and a group skips the thirds it has nothing in (the rest of a third is zero fill).
-  int klo[4], khi[4];
-#pragma unroll
-  for (int g = 0; g < 4; g++) {
-    const long long lo = __shfl(c0, g * 16, 64), hi = __shfl(c1, g * 16, 64);
-    klo[g] = hi < 0 ? kMfmaSteps : (int)((lo - cmin) >> 2);
-    khi[g] = hi < 0 ? -1 : (int)((hi - cmin) >> 2);
-  }
+  // the same in every lane: kept in scalar registers, and everything below is relative to it in 32 bits
+  int64_t cmin;
+  if (sizeof(I) == 4) cmin = (int64_t)__builtin_amdgcn_readfirstlane((int)cmin_v);
+  else cmin = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((long long)cmin_v >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)cmin_v));
+  const int rel0 = c1 < 0 ? 0x3fffffff : (int)(c0 - cmin_v), rel1 = c1 < 0 ? -1 : (int)(c1 - cmin_v);  // of this lane's group
 
   const int kq = lane >> 4, jc = lane & 15;
   // B fragments of the window for this wavefront's 16 columns: rows cmin + 4 kk + kq, column j.  Rows past
   // the matrix and columns past k are clamped to valid addresses: their products meet the zero fill / are
-  // never stored.
+  // never stored.  Byte offsets inside the window fit 32 bits (checked by the host).
+  const char *Bwin = reinterpret_cast<const char *>(B + cmin * k);
+  const uint32_t rowbytes = (uint32_t)k * (uint32_t)sizeof(T);
+  const int wlast = (int)((m - cmin) < (int64_t)(kWinRows + 4) ? (m - cmin) : (int64_t)(kWinRows + 4)) - 1;
   T b[kMfmaSteps];
   auto load_b = [&](int64_t j) {
-    const int64_t jj = j < k ? j : k - 1;
+    const uint32_t jb = (uint32_t)(j < k ? j : k - 1) * (uint32_t)sizeof(T);
 #pragma unroll
     for (int kk = 0; kk < kMfmaSteps; kk++) {
-      int64_t row = cmin + kk * 4 + kq;
-      row = row < m ? row : m - 1;
-      b[kk] = B[row * k + jj];
+      const int w = kk * 4 + kq;
+      const uint32_t off = (uint32_t)(w < wlast ? w : wlast) * rowbytes + jb;
+      b[kk] = *reinterpret_cast<const T *>(Bwin + off);
     }
   };
   const int64_t cb0 = 16 * wave;
-  if (cb0 < k) load_b(cb0 + jc);  // first strip: the loads fly while the dense blocks are built
+  const bool single = k <= 64;  // one strip: its B fragments are requested once, before the first block is built
+  if (single && cb0 < k) load_b(cb0 + jc);
 
-  for (int jr = slot; jr < nrows; jr += 16) {
+  // row jr = 16 g + slot of group g is laid out (or wiped) by the 16 lanes of its slot
+  const int cmin32 = (int)cmin;  // only used when columns are stored in 32 bits
+  auto lay = [&](int g, T *buf, bool wipe) {
+    const int jr = g * 16 + slot;
+    if (jr >= nrows) return;
     const int rs = srel[jr], re = srel[jr + 1];
     const int s = rs > 0 ? rs : 0;
     const int e = re < cnt ? re : cnt;
-    const int g = jr >> 4, rr = jr & 15;
-    for (int q = s + cg; q < e; q += 16) Ad[(g * kWinRows + (int)((long long)scol[q] - cmin)) * 16 + rr] = sval[q];
-  }
+    for (int q = s + cg; q < e; q += 16) {
+      const int w = sizeof(I) == 4 ? (int)scol[q] - cmin32 : (int)((int64_t)scol[q] - cmin);
+      buf[w * 16 + slot] = wipe ? (T)0 : sval[q];
+    }
+  };
+  lay(0, Ad, false);
   __syncthreads();
 
   constexpr int kThird = kMfmaSteps / 3;
-  for (int64_t cb = cb0; cb < k; cb += 64) {
-    const int64_t j = cb + jc;
-    const bool jl = j < k;
-    if (cb != cb0) load_b(j);
-    bool bad = false;
+  const bool enters = lb0 > 0;  // row rfirst started in an earlier tile: its part here goes to head[t], if any
+  const bool enters_live = enters && srel[1] > 0;
+  for (int g = 0; g < ngroups; g++) {
+    const T *cur = Ad + (g & 1) * kBuf;
+    if (g + 1 < ngroups) {
+      T *nxt = Ad + ((g + 1) & 1) * kBuf;
+      if (g >= 1) lay(g - 1, nxt, true);
+      lay(g + 1, nxt, false);
+    }
+    // MFMA steps (4 window columns each) holding entries of the group; the window's 18 steps are walked
+    // in thirds and a group skips the thirds it has nothing in (the rest of a third is zero fill)
+    const int klo = __builtin_amdgcn_readfirstlane(__shfl(rel0, g * 16, 64)) >> 2;
+    const int khi = __builtin_amdgcn_readfirstlane(__shfl(rel1, g * 16, 64)) >> 2;
+    // this lane's rows of the group: jr = 16 g + row(lane, i)
+    T *Cg = C + (rfirst + g * 16) * k;
+    for (int64_t cb = cb0; cb < k; cb += 64) {
+      const int64_t j = cb + jc;
+      const bool jl = j < k;
+      if (!single) load_b(j);
+      acc_t acc = acc_t{(T)0, (T)0, (T)0, (T)0};
 #pragma unroll
-    for (int kk = 0; kk < kMfmaSteps; kk++) bad = bad || Mfma<T>::nonfinite(b[kk]);
-    const bool nf = __any(bad);
+      for (int h = 0; h < 3; h++) {
+        if (klo < (h + 1) * kThird && khi >= h * kThird) {  // uniform
+          T a[kThird];
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      if (g >= ngroups) continue;
-      if (nf) {
-        // a non-finite value of B in the window: 0 * inf of the zero fill must not reach C, so these
-        // 16 rows x 16 columns are multiplied entry by entry
+          for (int i = 0; i < kThird; i++) a[i] = cur[((h * kThird + i) * 4 + kq) * 16 + jc];
+#pragma unroll
+          for (int i = 0; i < kThird; i++) acc = Mfma<T>::mma(a[i], b[h * kThird + i], acc);
+        }
+      }
+      const bool bad = Mfma<T>::nonfinite(acc[0]) || Mfma<T>::nonfinite(acc[1]) || Mfma<T>::nonfinite(acc[2]) ||
+                       Mfma<T>::nonfinite(acc[3]);
+      if (__any(bad)) {
+        // a non-finite result: it may be 0 * inf of the zero fill (a non-finite value in a row of B the
+        // matrix row does not reference), which must not reach C; these 16 rows x 16 columns are multiplied
+        // again entry by entry
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int jr = g * 16 + kq + 4 * i;
@@ -550,29 +585,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
         }
         continue;
       }
-      acc_t acc = acc_t{(T)0, (T)0, (T)0, (T)0};
-#pragma unroll
-      for (int h = 0; h < 3; h++) {
-        if (klo[g] < (h + 1) * kThird && khi[g] >= h * kThird) {  // uniform
-          T a[kThird];
-#pragma unroll
-          for (int i = 0; i < kThird; i++) a[i] = Ad[(g * kWinRows + (h * kThird + i) * 4 + kq) * 16 + jc];
-#pragma unroll
-          for (int i = 0; i < kThird; i++) acc = Mfma<T>::mma(a[i], b[h * kThird + i], acc);
-        }
-      }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int jr = g * 16 + Mfma<T>::row(lane, i);
+        const int jl16 = Mfma<T>::row(lane, i);  // row inside the group
+        const int jr = g * 16 + jl16;
         if (jr < nrows && jl) {
-          const int rs = srel[jr], re = srel[jr + 1];
-          const int64_t r = rfirst + jr;
-          if (r < lb0 && re <= 0) continue;
-          if (rs >= 0) __builtin_nontemporal_store(acc[i], C + r * k + j);
-          else head[t * k + j] = acc[i];
+          if (jr == 0 && enters) {
+            if (enters_live) head[t * k + j] = acc[i];
+          } else {
+            __builtin_nontemporal_store(acc[i], Cg + (uint32_t)jl16 * (uint32_t)k + j);
+          }
         }
       }
     }
+    if (g + 1 < ngroups) __syncthreads();
   }
 }
 
@@ -598,6 +624,40 @@ __global__ __launch_bounds__(64) void spmm_fixup_kernel(const int64_t *__restric
   }
 }
 
+// First product of a record: classify its tiles and split the tile ids into the dense-block tiles
+// (first n_mfma_tiles of tile_split, ascending) and the rest.  One-off: the class bytes take a round trip
+// through the host.
+template <class T, class I>
+int spmm_classify(futhark_context *ctx, const CsrBody<T> *a, const I *col) {
+  if (a->n_mfma_tiles >= 0) return 0;
+  Tmp<uint8_t> cls(ctx);
+  SAMD_TRY(cls.get(a->ntiles));
+  SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+  hipLaunchKernelGGL((spmm_classify_kernel<I, kSpmvTile>), dim3((unsigned)a->ntiles), dim3(64), 0, ctx->stream, col,
+                     (const int64_t *)a->tile_lb, a->nnz, a->ntiles, cls.p,
+                     reinterpret_cast<unsigned long long *>(ctx->d_small));
+  SAMD_LAUNCH_CHECK(ctx);
+  int64_t nm = 0;
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, &nm));
+  if (nm > 0) {
+    std::vector<uint8_t> h((size_t)a->ntiles);
+    SAMD_HIP(ctx, hipMemcpyAsync(h.data(), cls.p, (size_t)a->ntiles, hipMemcpyDeviceToHost, ctx->stream));
+    SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> split((size_t)a->ntiles);
+    size_t i0 = 0, i1 = (size_t)nm;
+    for (int64_t t = 0; t < a->ntiles; t++) {
+      if (h[(size_t)t]) split[i0++] = (int32_t)t;
+      else split[i1++] = (int32_t)t;
+    }
+    SAMD_TRY(dalloc(ctx, &a->tile_split, a->ntiles));
+    SAMD_HIP(ctx, hipMemcpyAsync(a->tile_split, split.data(), sizeof(int32_t) * (size_t)a->ntiles, hipMemcpyHostToDevice,
+                                 ctx->stream));
+    SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // split is a local
+  }
+  a->n_mfma_tiles = nm;
+  return 0;
+}
+
 template <class T, class I>
 int spmm_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T *B, int64_t k, T *C) {
   if (ctx->opt_spmm_algo == 2) {
@@ -618,39 +678,32 @@ int spmm_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
   // 16-byte accesses need every row of B, C and of the head rows 16-byte aligned
   const bool vec = ((k * sizeof(T)) % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0);
   const int flags = (int)ctx->opt_ablate;
-  const uint8_t *cls = nullptr;
+  const int32_t *vec_list = nullptr;
+  int64_t nvec = a->ntiles;
   if constexpr (Mfma<T>::ok) {
-    if (ctx->opt_spmm_algo != 3) {  // spmm_algo 3: never the matrix cores
-      if (a->n_mfma_tiles < 0) {
-        SAMD_TRY(dalloc(ctx, &a->tile_class, a->ntiles));
-        SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
-        hipLaunchKernelGGL((spmm_classify_kernel<I, kSpmvTile>), dim3((unsigned)a->ntiles), dim3(64), 0, ctx->stream, col,
-                           (const int64_t *)a->tile_lb, a->nnz, a->ntiles, a->tile_class,
-                           reinterpret_cast<unsigned long long *>(ctx->d_small));
-        SAMD_LAUNCH_CHECK(ctx);
-        int64_t cnt = 0;
-        SAMD_TRY(read_small(ctx, ctx->d_small, 1, &cnt));
-        a->n_mfma_tiles = cnt;
-      }
+    // spmm_algo 3: never the matrix cores; the kernel addresses a B window with 32-bit byte offsets
+    if (ctx->opt_spmm_algo != 3 && a->ntiles < 0x7fffffffLL && k * (int64_t)sizeof(T) * (kWinRows + 8) < 0x7fffffffLL) {
+      SAMD_TRY((spmm_classify<T, I>(ctx, a, col)));
       if (a->n_mfma_tiles > 0) {
-        cls = a->tile_class;
-        hipLaunchKernelGGL((spmm_mfma_kernel<T, I, kSpmvTile>), dim3((unsigned)a->ntiles), dim3(kBlock), 0, ctx->stream,
-                           (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C, (const int64_t *)a->tile_lb,
-                           head.p, cls, a->nnz, a->ntiles, k, a->m);
+        hipLaunchKernelGGL((spmm_mfma_kernel<T, I, kSpmvTile>), dim3((unsigned)a->n_mfma_tiles), dim3(kBlock), 0,
+                           ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C,
+                           (const int64_t *)a->tile_lb, head.p, (const int32_t *)a->tile_split, a->n_mfma_tiles, a->nnz,
+                           k, a->m);
         SAMD_LAUNCH_CHECK(ctx);
+        vec_list = a->tile_split + a->n_mfma_tiles;
+        nvec = a->ntiles - a->n_mfma_tiles;
       }
     }
   }
-  const bool all_mfma = cls && a->n_mfma_tiles == a->ntiles;
-  if (all_mfma) {
+  if (nvec == 0) {
   } else if (vec)
-    hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, true>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
+    hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, true>), dim3((unsigned)nvec), dim3(kBlock), 0,
                        ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C,
-                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, flags, cls);
+                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, flags, vec_list, nvec);
   else
-    hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, false>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,
+    hipLaunchKernelGGL((spmm_stream_kernel<T, I, kSpmvTile, false>), dim3((unsigned)nvec), dim3(kBlock), 0,
                        ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, B, C,
-                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, flags, cls);
+                       (const int64_t *)a->tile_lb, head.p, a->nnz, a->ntiles, k, flags, vec_list, nvec);
   SAMD_LAUNCH_CHECK(ctx);
   if (a->ntiles > 1) {
     hipLaunchKernelGGL((spmm_fixup_kernel<T, kSpmvTile>), dim3((unsigned)(a->ntiles - 1)), dim3(64), 0, ctx->stream,
