@@ -2,9 +2,9 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_c4
 mkdir -p $OUT
-i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
-  i=$((i+1))
+CGRP=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum")
+for i in ${PASSES:-0 1 2 3 4}; do
+  grp=${CGRP[$i]}
   timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -o p -- python3 $GRAFT_REPO_ROOT/bench/configs.py c4 --steps 10 > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; exit 1; }
   python3 - "$OUT/p$i/p_counter_collection.csv" <<'PY'
 import csv, sys, collections

@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "lib", "libsparse_amd.so")
+_LIBPATH = os.environ.get("SPARSE_AMD_LIB") or os.path.join(_HERE, "lib", "libsparse_amd.so")  # override: kernel-lab builds
 _lib = None
 
 _CT = {"f64": ctypes.c_double, "f32": ctypes.c_float, "i32": ctypes.c_int32, "i64": ctypes.c_int64}

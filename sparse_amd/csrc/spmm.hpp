@@ -79,6 +79,7 @@ constexpr int kWinRows = 72;    // rows of B (x 64 columns) staged per tile
 constexpr int kMfmaMinLen = 16; // mean row-fragment length from which a banded tile goes to the matrix cores
 constexpr int kMfmaSteps = kWinRows / 4;
 
+
 template <class T>
 struct Mfma { static constexpr bool ok = false; };
 template <>
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void spmm_mfma_kernel(
   lay(0, Ad, false);
   __syncthreads();
 
-  constexpr int kThird = kMfmaSteps / 3;
+  constexpr int kSect = 6;  // MFMA steps per section (3 and 1 measured the same: the MFMA count is not the bound)
   const bool enters = lb0 > 0;  // row rfirst started in an earlier tile: its part here goes to head[t], if any
   const bool enters_live = enters && srel[1] > 0;
   for (int g = 0; g < ngroups; g++) {
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(kBlock) void spmm_mfma_kernel(
       lay(g + 1, nxt, false);
     }
     // MFMA steps (4 window columns each) holding entries of the group; the window's 18 steps are walked
-    // in thirds and a group skips the thirds it has nothing in (the rest of a third is zero fill)
+    // in sections of kSect and a group skips the sections it has nothing in (the rest of a section is zero fill)
     const int klo = __builtin_amdgcn_readfirstlane(__shfl(rel0, g * 16, 64)) >> 2;
     const int khi = __builtin_amdgcn_readfirstlane(__shfl(rel1, g * 16, 64)) >> 2;
     // this lane's rows of the group: jr = 16 g + row(lane, i)
@@ -555,13 +556,13 @@ __global__ __launch_bounds__(kBlock) void spmm_mfma_kernel(
       if (!single) load_b(j);
       acc_t acc = acc_t{(T)0, (T)0, (T)0, (T)0};
 #pragma unroll
-      for (int h = 0; h < 3; h++) {
-        if (klo < (h + 1) * kThird && khi >= h * kThird) {  // uniform
-          T a[kThird];
+      for (int h = 0; h < kMfmaSteps / kSect; h++) {
+        if (klo < (h + 1) * kSect && khi >= h * kSect) {  // uniform
+          T a[kSect];
 #pragma unroll
-          for (int i = 0; i < kThird; i++) a[i] = cur[((h * kThird + i) * 4 + kq) * 16 + jc];
+          for (int i = 0; i < kSect; i++) a[i] = cur[((h * kSect + i) * 4 + kq) * 16 + jc];
 #pragma unroll
-          for (int i = 0; i < kThird; i++) acc = Mfma<T>::mma(a[i], b[h * kThird + i], acc);
+          for (int i = 0; i < kSect; i++) acc = Mfma<T>::mma(a[i], b[h * kSect + i], acc);
         }
       }
       const bool bad = Mfma<T>::nonfinite(acc[0]) || Mfma<T>::nonfinite(acc[1]) || Mfma<T>::nonfinite(acc[2]) ||
