@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--spmm-algo", type=int, default=0)
+    ap.add_argument("--cblk", type=int, default=0, help="spmv_cblk option: -1 never, W > 0 force W columns per block")
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--compare", action="store_true", help="also time torch.sparse (rocSPARSE) CSR SpMV as a comparator")
@@ -46,6 +47,8 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.algo:
         ctx.set_option("spmv_algo", args.algo)
+    if args.cblk:
+        ctx.set_option("spmv_cblk", args.cblk)
     if args.spmm_algo:
         ctx.set_option("spmm_algo", args.spmm_algo)
     if args.lanes:
@@ -145,6 +148,12 @@ def main():
         elif cfg == "c5":
             run("C5 random n=1e7 nnz0=1e9 (one GPU)", "f64", 10**7, 10**7,
                 lambda: synth.random_uniform_coo_device(10**7, 10**7, 10**9, dev))
+        elif cfg == "c5r":   # what one of 8 ranks holds after row sharding: an eighth of the rows, every column
+            run("C5 row shard 1/8: random 1.25e6 x 1e7, nnz0=1.25e8", "f64", 1250000, 10**7,
+                lambda: synth.random_uniform_coo_device(1250000, 10**7, 125 * 10**6, dev))
+        elif cfg == "c5q":   # kernel lab: few enough panels for one round of resident workgroups
+            run("lab: random 5e5 x 1e7, nnz0=5e7", "f64", 500000, 10**7,
+                lambda: synth.random_uniform_coo_device(500000, 10**7, 50 * 10**6, dev))
         elif cfg == "c5s":
             run("C5-shard random n=1e7 nnz0=1.25e8", "f64", 10**7, 10**7,
                 lambda: synth.random_uniform_coo_device(10**7, 10**7, 125 * 10**6, dev))

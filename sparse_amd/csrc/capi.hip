@@ -522,6 +522,7 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_lanes")) ctx->opt_spmv_lanes = value;
   else if (!strcmp(key, "wide_col")) ctx->opt_wide_col = value;
   else if (!strcmp(key, "spmm_algo")) ctx->opt_spmm_algo = value;
+  else if (!strcmp(key, "spmv_cblk")) ctx->opt_spmv_cblk = value;
   else if (!strcmp(key, "sort_algo")) ctx->opt_sort_algo = value;
   else if (!strcmp(key, "spmv_reorder")) ctx->opt_spmv_reorder = value;
   else if (!strcmp(key, "ablate")) ctx->opt_ablate = value;
@@ -534,6 +535,7 @@ int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *k
   if (!strcmp(key, "spmv_lanes")) return ctx->opt_spmv_lanes;
   if (!strcmp(key, "wide_col")) return ctx->opt_wide_col;
   if (!strcmp(key, "spmm_algo")) return ctx->opt_spmm_algo;
+  if (!strcmp(key, "spmv_cblk")) return ctx->opt_spmv_cblk;
   if (!strcmp(key, "sort_algo")) return ctx->opt_sort_algo;
   if (!strcmp(key, "spmv_reorder")) return ctx->opt_spmv_reorder;
   if (!strcmp(key, "num_cu")) return ctx->num_cu;

@@ -113,6 +113,7 @@ struct futhark_context {
   int64_t opt_wide_col = 0;
   int64_t opt_spmv_tile = 0;
   int64_t opt_spmm_algo = 0;
+  int64_t opt_spmv_cblk = 0;  // 0 auto, > 0 always with this many columns per block, -1 never
   int64_t opt_spmv_reorder = 0;  // 0 auto, 1 always (when the record qualifies by size), -1 never
   int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
@@ -237,6 +238,14 @@ struct CsrBody {
   mutable int32_t *col_hot = nullptr;    // [nnz] rank of each entry's column by popularity
   mutable uint32_t *hot_perm = nullptr;  // [m]   hot_perm[rank] = column
   mutable T *x_hot = nullptr;            // [m]   x gathered into rank order, rewritten by every product
+  // column-blocked copy for gather-bound SpMV on flat, wide matrices (spmv.hpp, "column blocks"); built lazily
+  mutable bool gather_flat = false;  // the renumbering was rejected because column popularity is flat
+  mutable int cblk_state = 0;        // 0 undecided, 1 active, -1 rejected
+  mutable int64_t cblk_nb = 0;       // column blocks
+  mutable int64_t *cblk_piece_ptr = nullptr;  // [panels * nb + 1] start of every piece
+  mutable uint16_t *cblk_end = nullptr;       // [panels * nb * rows per panel] end of each row inside its piece
+  mutable int32_t *cblk_col = nullptr;        // [nnz] entries in piece order
+  mutable T *cblk_val = nullptr;
   // SpMM: tiles that go to the matrix cores (spmm.hpp), decided at the first product
   mutable int32_t *tile_split = nullptr;  // [ntiles] ids of the dense-block tiles, then of the others
   mutable int64_t n_mfma_tiles = -1;
@@ -257,6 +266,10 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->hot_perm);
   dfree(ctx, b->x_hot);
   dfree(ctx, b->tile_split);
+  dfree(ctx, b->cblk_piece_ptr);
+  dfree(ctx, b->cblk_end);
+  dfree(ctx, b->cblk_col);
+  dfree(ctx, b->cblk_val);
   delete b;
 }
 

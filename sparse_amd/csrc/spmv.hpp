@@ -397,7 +397,7 @@ int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
   int64_t h2[3];
   if (read_small(ctx, ctx->d_small, 3, h2) != 0) { dfree(ctx, hot_perm); return 1; }
   if ((int)(h2[2] & 0xffffffff) != 0) { dfree(ctx, hot_perm); return set_error(ctx, "internal: radix sort look-back timed out"); }
-  if (!force && h2[0] * 2 < a->nnz) { dfree(ctx, hot_perm); return 0; }  // flat popularity: nothing to pack
+  if (!force && h2[0] * 2 < a->nnz) { dfree(ctx, hot_perm); a->gather_flat = true; return 0; }  // flat popularity: nothing to pack
   int32_t *col_hot = nullptr;
   T *x_hot = nullptr;
   if (dalloc(ctx, &col_hot, a->nnz) != 0 || dalloc(ctx, &x_hot, a->m) != 0) {
@@ -411,6 +411,187 @@ int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
   a->col_hot = col_hot;
   a->x_hot = x_hot;
   a->reorder_state = 1;
+  return 0;
+}
+
+// ------------------------------------------------------------- column blocks
+// Wide matrices with flat column popularity (uniform random: BASELINE configs[4]) are bound by the x gather
+// as well, but no renumbering helps: every gather misses the L2s and each miss moves a whole line over the
+// fabric (measured: 1e9 f64 gathers run at the rate of ~128 B each).  Such a record gets, at its first
+// product, a second copy of its entries cut into PIECES: (panel of kCblkRows rows) x (block of columns whose
+// slice of x, kCblkBytes, stays in every XCD's L2), entries of a piece contiguous and in (row, column) order,
+// the pieces of a column block consecutive.  A product is one launch per column block, in ascending order,
+// workgroup = piece, y += A_b x: all gathers of a launch fall into one slice and hit L2; a row's entries are
+// added strictly left to right (the oracle's order); no atomics, no fix-up.  Per piece and row there is one
+// 16-bit end offset (cblk_end) and y is read and written once per block that holds entries of the row,
+// which is why auto mode wants about one entry per row and block on average.
+// Measured (f64, uniform random, m = 1e7, 100 entries per row): 1.25e6 rows 2.37 -> 1.04 ms, 1e7 rows
+// (1e9 entries) 19.0 -> 6.3 ms.  What remains is the rate at which a CU turns over L1 misses that hit L2
+// (~140 G gathers/s chip-wide), not HBM.
+constexpr int64_t kCblkBytes = 2 << 20;
+constexpr int kCblkRpt = 4;                   // rows per thread
+constexpr int kCblkRows = kBlock * kCblkRpt;  // rows per panel (one workgroup)
+constexpr int kCblkCap = 4096;                // products staged in LDS at a time
+
+__device__ __forceinline__ int64_t cblk_lower_bound(const int32_t *__restrict__ col, int64_t lo, int64_t hi, int64_t c) {
+  while (lo < hi) {  // first position in [lo, hi) whose column is >= c
+    const int64_t mid = lo + (hi - lo) / 2;
+    if ((int64_t)col[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// grid = pieces (block-major), thread = kCblkRpt consecutive rows of the panel.  COPY=false: per-row end
+// offsets inside the piece and the piece's size; COPY=true: the entries move to their place.
+template <class T, bool COPY>
+__global__ __launch_bounds__(kBlock) void cblk_build_kernel(const int64_t *__restrict__ row_ptr,
+                                                            const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                            int64_t n, int64_t m, int64_t nb, int64_t width,
+                                                            uint16_t *__restrict__ row_end,
+                                                            int64_t *__restrict__ piece_ptr /* COPY: starts; else [1 + piece] sizes */,
+                                                            int32_t *__restrict__ pc_col, T *__restrict__ pc_val,
+                                                            int *__restrict__ too_big) {
+  __shared__ int64_t sh[kWaves];
+  const int64_t piece = blockIdx.x, panels = gridDim.x / nb;  // block-major: a launch of the product reads one run
+  const int64_t b = piece / panels, p = piece - b * panels;
+  const int64_t r0 = p * kCblkRows + (int64_t)threadIdx.x * kCblkRpt;
+  const int64_t clo = b * width, chi = (b + 1) * width < m ? (b + 1) * width : m;
+  int64_t s[kCblkRpt], cnt[kCblkRpt], mine = 0;
+#pragma unroll
+  for (int j = 0; j < kCblkRpt; j++) {
+    s[j] = 0;
+    cnt[j] = 0;
+    if (r0 + j < n) {
+      const int64_t rs = row_ptr[r0 + j], re = row_ptr[r0 + j + 1];
+      s[j] = cblk_lower_bound(col, rs, re, clo);
+      cnt[j] = cblk_lower_bound(col, s[j], re, chi) - s[j];
+    }
+    mine += cnt[j];
+  }
+  int64_t v[1] = {mine}, total;
+  block_scan_striped<int64_t, OpAdd, 1>(v, (int64_t)0, OpAdd(), sh, total);
+  int64_t off = v[0] - mine;  // entries of the piece before this thread's rows
+  if (!COPY) {
+    if (total > 65535 && threadIdx.x == 0) *too_big = 1;
+#pragma unroll
+    for (int j = 0; j < kCblkRpt; j++) {
+      off += cnt[j];
+      row_end[piece * kCblkRows + threadIdx.x * kCblkRpt + j] = (uint16_t)(off > 65535 ? 65535 : off);
+    }
+    if (threadIdx.x == 0) piece_ptr[1 + piece] = total;
+  } else {
+    int64_t dst = piece_ptr[piece] + off;
+#pragma unroll
+    for (int j = 0; j < kCblkRpt; j++)
+      for (int64_t q = 0; q < cnt[j]; q++, dst++) {
+        pc_col[dst] = col[s[j] + q];
+        pc_val[dst] = val[s[j] + q];
+      }
+  }
+}
+
+// One launch per column block (the launch boundary is what keeps all workgroups on the same slice of x:
+// a single persistent sweep drifts apart by more than a block within the dispatch skew alone and then
+// every gather misses L2 again -- measured).  Workgroup = piece.  Entry-parallel gather: every thread fetches
+// a few entries of the piece, gathers their x values (all gathers of the piece in flight at once, whatever
+// the row lengths) and leaves the products in LDS; after the barrier thread = row adds its products from
+// the left and adds the sum to y (first block: stores it).  Rows without entries in the block are skipped.
+template <class T>
+__global__ __launch_bounds__(kBlock) void spmv_cblk_kernel(const int64_t *__restrict__ piece_ptr,
+                                                           const uint16_t *__restrict__ row_end,
+                                                           const int32_t *__restrict__ pc_col,
+                                                           const T *__restrict__ pc_val, const T *__restrict__ x,
+                                                           T *__restrict__ y, int64_t n, int64_t panels, int64_t b) {
+  constexpr int E = kCblkCap / kBlock;  // entries per thread and chunk
+  __shared__ T sprod[kCblkCap];
+  const int tid = threadIdx.x;
+  const int64_t piece = b * panels + blockIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * kCblkRows + (int64_t)tid * kCblkRpt;
+  const int64_t ps = piece_ptr[piece];
+  const int cnt = (int)(piece_ptr[piece + 1] - ps);
+  int ends[kCblkRpt + 1];  // ends[j]: where row j of this thread starts, ends[j + 1]: where it ends
+  {
+    const uint16_t *re = row_end + piece * kCblkRows + (int64_t)tid * kCblkRpt;
+    ends[0] = tid ? (int)re[-1] : 0;
+#pragma unroll
+    for (int j = 0; j < kCblkRpt; j++) ends[j + 1] = (int)re[j];
+  }
+  T acc[kCblkRpt];
+#pragma unroll
+  for (int j = 0; j < kCblkRpt; j++) {
+    acc[j] = (T)0;
+    if (b > 0 && ends[j + 1] > ends[j]) acc[j] = y[r0 + j];  // requested now, needed after the gather
+  }
+  for (int c0 = 0; c0 < cnt; c0 += kCblkCap) {
+    const int cc = cnt - c0 < kCblkCap ? cnt - c0 : kCblkCap;
+    int32_t c[E];
+    T v[E], xv[E];
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+      const int e = tid + i * kBlock;
+      const bool ok = e < cc;
+      c[i] = ok ? ntload(&pc_col[ps + c0 + e]) : -1;
+      v[i] = ok ? ntload(&pc_val[ps + c0 + e]) : (T)0;
+    }
+#pragma unroll
+    for (int i = 0; i < E; i++) xv[i] = c[i] >= 0 ? x[c[i]] : (T)0;
+    if (c0) __syncthreads();  // the previous chunk's readers are done
+#pragma unroll
+    for (int i = 0; i < E; i++) sprod[tid + i * kBlock] = (T)(v[i] * xv[i]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kCblkRpt; j++) {
+      const int qs = (ends[j] > c0 ? ends[j] : c0) - c0, qe = (ends[j + 1] < c0 + cc ? ends[j + 1] : c0 + cc) - c0;
+      for (int q = qs; q < qe; q++) acc[j] = (T)(acc[j] + sprod[q]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kCblkRpt; j++)
+    if (r0 + j < n && (b == 0 || ends[j + 1] > ends[j])) y[r0 + j] = acc[j];
+}
+
+template <class T>
+int cblk_prepare(futhark_context *ctx, const CsrBody<T> *a) {
+  a->cblk_state = -1;
+  if (ctx->opt_spmv_cblk < 0 || !a->col32 || a->nnz == 0 || a->n == 0) return 0;
+  const bool force = ctx->opt_spmv_cblk > 0;  // tests: any size, block width in columns given by the option
+  int64_t width = force ? ctx->opt_spmv_cblk : kCblkBytes / (int64_t)sizeof(T);
+  const int64_t nb = cdiv(a->m, width);
+  // measured break-even near 0.4 entries per row and block (n = m = 1e7: 12.5 per row, 39 blocks: 2.61 vs 2.41 ms)
+  if (!force && (!a->gather_flat || nb < 4 || 4 * a->nnz < 3 * a->n * nb)) return 0;
+  width = cdiv(a->m, nb);
+  const int64_t panels = cdiv(a->n, kCblkRows), pieces = panels * nb;
+  if (pieces >= 0x7fffffffLL) return 0;
+  Tmp<int64_t> piece_ptr(ctx);
+  Tmp<uint16_t> row_end(ctx);
+  Tmp<int32_t> pc_col(ctx);
+  Tmp<T> pc_val(ctx);
+  SAMD_TRY(piece_ptr.get(pieces + 1));
+  SAMD_TRY(row_end.get(pieces * kCblkRows));
+  SAMD_TRY(pc_col.get(a->nnz));
+  SAMD_TRY(pc_val.get(a->nnz));
+  int *flag = reinterpret_cast<int *>(ctx->d_small);
+  SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+  SAMD_HIP(ctx, hipMemsetAsync(piece_ptr.p, 0, sizeof(int64_t), ctx->stream));
+  hipLaunchKernelGGL((cblk_build_kernel<T, false>), dim3((unsigned)pieces), dim3(kBlock), 0, ctx->stream,
+                     (const int64_t *)a->row_ptr, (const int32_t *)a->col32, (const T *)a->vals, a->n, a->m, nb, width,
+                     row_end.p, piece_ptr.p, pc_col.p, pc_val.p, flag);
+  SAMD_LAUNCH_CHECK(ctx);
+  int64_t host = 0;
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, &host));
+  if ((int)(host & 0xffffffff) != 0) return 0;  // a piece too large for 16-bit offsets: rows far too uneven for this path
+  SAMD_TRY((device_scan<int64_t, OpAdd, PtrIn<int64_t>, false>(ctx, PtrIn<int64_t>{piece_ptr.p + 1}, pieces, (int64_t)0,
+                                                                OpAdd(), piece_ptr.p + 1, (int64_t *)nullptr)));
+  hipLaunchKernelGGL((cblk_build_kernel<T, true>), dim3((unsigned)pieces), dim3(kBlock), 0, ctx->stream,
+                     (const int64_t *)a->row_ptr, (const int32_t *)a->col32, (const T *)a->vals, a->n, a->m, nb, width,
+                     row_end.p, piece_ptr.p, pc_col.p, pc_val.p, flag);
+  SAMD_LAUNCH_CHECK(ctx);
+  a->cblk_nb = nb;
+  a->cblk_piece_ptr = piece_ptr.release();
+  a->cblk_end = row_end.release();
+  a->cblk_col = pc_col.release();
+  a->cblk_val = pc_val.release();
+  a->cblk_state = 1;
   return 0;
 }
 
@@ -502,6 +683,17 @@ int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
                        x, (const uint32_t *)a->hot_perm, a->m, a->x_hot);
     SAMD_LAUNCH_CHECK(ctx);
     return spmv_typed<T, int32_t>(ctx, a, a->col_hot, (const T *)a->x_hot, y);
+  }
+  if ((algo == 0 || algo == 1) && a->reorder_state == -1 && a->cblk_state == 0) SAMD_TRY(cblk_prepare<T>(ctx, a));
+  if ((algo == 0 || algo == 1) && a->cblk_state == 1) {
+    const int64_t panels = cdiv(a->n, kCblkRows);
+    for (int64_t b = 0; b < a->cblk_nb; b++) {
+      hipLaunchKernelGGL((spmv_cblk_kernel<T>), dim3((unsigned)panels), dim3(kBlock), 0, ctx->stream,
+                         (const int64_t *)a->cblk_piece_ptr, (const uint16_t *)a->cblk_end,
+                         (const int32_t *)a->cblk_col, (const T *)a->cblk_val, x, y, a->n, panels, b);
+      SAMD_LAUNCH_CHECK(ctx);
+    }
+    return 0;
   }
   if (a->col32) return spmv_typed<T, int32_t>(ctx, a, a->col32, x, y);
   return spmv_typed<T, int64_t>(ctx, a, a->col64, x, y);

@@ -277,6 +277,33 @@ def test_smvm_hot_column_renumbering_is_bit_identical(ctx, dtype):
     close(ys[0], O.sr_smvm(O.sr_sparse(n, m, r, c, v), x), dtype)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+@pytest.mark.parametrize("width", [512, 4096])
+def test_smvm_column_blocks(ctx, dtype, width):
+    """spmv_cblk=W forces the column-blocked product (normally kept for wide matrices with flat column
+    popularity): the record is split into blocks of W columns and y accumulates block by block.  Against the
+    oracle; i32 exact; reproducible; second product on the cached split with another x; a matrix whose first
+    block is empty; rows longer than a tile, empty rows and runs of them."""
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    ctx.set_option("spmv_cblk", width)
+    try:
+        for n, m, gen in ((3000, 9000, lambda: skewed_coo(3000, 9000, dtype, 8)),
+                          (20000, 5000, lambda: random_coo(20000, 5000, 90000, dtype, seed=91, dup_frac=0.05)),
+                          (700, 6000, lambda: tuple(a if i != 1 else a + 1500 for i, a in
+                                                    enumerate(random_coo(700, 4500, 20000, dtype, seed=92))))):
+            r, c, v = gen()
+            A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
+            x = synth.uniform_values(5, m, dtype)
+            y0 = M.sr.smvm(A, x).numpy()
+            close(y0, O.sr_smvm(Ao, x), dtype)
+            assert M.sr.smvm(A, x).numpy().tobytes() == y0.tobytes()
+            x2 = synth.uniform_values(6, m, dtype)
+            close(M.sr.smvm(A, x2), O.sr_smvm(Ao, x2), dtype)
+            assert_same_record(A, Ao)                       # the record itself is untouched by the split
+    finally:
+        ctx.set_option("spmv_cblk", 0)
+
+
 @pytest.mark.parametrize("lanes", [0, 8])
 def test_smvm_long_runs_of_empty_rows(ctx, lanes):
     """Hundreds of thousands of empty rows before, between and after the stored ones: the tile that holds a
