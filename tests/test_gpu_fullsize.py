@@ -94,3 +94,86 @@ def test_dist_csr_single_rank_on_gpu():
     D.x_own.copy_(synth.laplacian_x_device(0, n, "cuda:0"))
     y = torch.as_tensor(D.smvm(), device="cuda:0")
     assert torch.equal(y, synth.laplacian_2d_apply_rows(g, g, 0, n, "cuda:0"))
+
+
+# ---- the other BASELINE configs at full size, through properties that need no oracle run at that size
+def _ctx():
+    import torch
+    from sparse_amd import Context
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    return torch, ctx
+
+
+def test_c4_smm_matrix_cores_against_the_entry_path_and_linearity():
+    """configs[3]: banded n = 2^20, 27 entries per row, k = 64, f64.  The dense-block (MFMA) tiles against the
+    same record multiplied entry by entry (spmm_algo 3): different kernels, different summation order, results
+    within 1e-12 relative (all values positive).  Column j of the product equals smvm with column j of the
+    panel (the definition), and the product is linear in the panel."""
+    torch, ctx = _ctx()
+    from sparse_amd import mk_compressed, synth
+    M = mk_compressed("f64", ctx)
+    n, k = 1 << 20, 64
+    r, c, v = synth.banded_coo_device(n, 13, "cuda:0")
+    A = M.sr.sparse(n, n, (r, c, v))
+    del r, c, v
+    B = torch.rand(n, k, device="cuda:0", dtype=torch.float64) + 0.5
+    C = torch.as_tensor(M.sr.smm(A, B), device="cuda:0").clone()
+    ctx.set_option("spmm_algo", 3)
+    try:
+        C3 = torch.as_tensor(M.sr.smm(A, B), device="cuda:0").clone()
+    finally:
+        ctx.set_option("spmm_algo", 0)
+    assert float(((C - C3).abs() / C3.abs()).max()) <= 1e-12
+    for j in (0, 17, 63):
+        yj = torch.as_tensor(M.sr.smvm(A, B[:, j].contiguous()), device="cuda:0")
+        assert float(((C[:, j] - yj).abs() / yj.abs()).max()) <= 1e-12
+    C2 = torch.as_tensor(M.sr.smm(A, 2.0 * B), device="cuda:0")
+    assert torch.equal(C2, 2.0 * C)          # scaling by a power of two is exact in every partial sum
+
+
+def test_c5_row_shard_column_blocks_against_the_plain_kernel():
+    """configs[4], what one of 8 ranks holds: uniform random 1.25e6 x 1e7, 1.25e8 triples, f64.  Auto mode
+    picks the column-blocked product for it; the same record with spmv_cblk -1 runs the plain streaming
+    kernel.  Different kernels and summation orders: within 1e-12 relative; the column-blocked one is
+    reproducible bit for bit."""
+    torch, ctx = _ctx()
+    from sparse_amd import mk_compressed, synth
+    M = mk_compressed("f64", ctx)
+    n, m = 1250000, 10**7
+    r, c, v = synth.random_uniform_coo_device(n, m, 125 * 10**6, "cuda:0")
+    x = torch.rand(m, device="cuda:0", dtype=torch.float64) + 0.5
+    A = M.sr.sparse(n, m, (r, c, v))
+    y = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0").clone()
+    y_again = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0")
+    assert torch.equal(y, y_again)
+    ctx.set_option("spmv_cblk", -1)
+    try:
+        A2 = M.sr.sparse(n, m, (r, c, v))       # a fresh record: the choice is made at a record's first product
+        y2 = torch.as_tensor(M.sr.smvm(A2, x), device="cuda:0")
+    finally:
+        ctx.set_option("spmv_cblk", 0)
+    assert float(((y - y2).abs() / y2.abs()).max()) <= 1e-12
+    # and against torch's own COO path on the same triples (independent of this library)
+    want = torch.zeros(n, device="cuda:0", dtype=torch.float64).index_add_(0, r, v * x[c])
+    assert float(((y - want).abs() / want.abs()).max()) <= 1e-12
+
+
+def test_c3_hot_column_renumbering_against_the_plain_kernel():
+    """configs[2] at scale 22 (same generator and skew as scale 24, a sixteenth of the entries so the module
+    stays within a few seconds): the renumbered product is bit-identical to the plain one."""
+    torch, ctx = _ctx()
+    from sparse_amd import mk_compressed, synth
+    M = mk_compressed("f32", ctx)
+    n = 1 << 22
+    r, c, v = synth.rmat_coo_device(22, 18, "cuda:0", "f32")
+    x = torch.rand(n, device="cuda:0", dtype=torch.float32) + 0.5
+    ys = []
+    for mode in (1, -1):
+        ctx.set_option("spmv_reorder", mode)
+        try:
+            A = M.sr.sparse(n, n, (r, c, v))
+            ys.append(torch.as_tensor(M.sr.smvm(A, x), device="cuda:0").clone())
+        finally:
+            ctx.set_option("spmv_reorder", 0)
+    assert torch.equal(ys[0], ys[1])
