@@ -508,10 +508,13 @@ void *sparse_amd_context_get_stream(struct futhark_context *ctx);
 /* Tuning / test overrides.  Keys: "spmv_algo" (0 auto, 1 nnz-split stream,
  * 2 wavefront-per-row, 3 sub-wavefront-per-row), "spmv_lanes" (sub-wavefront
  * width, power of two <= 64), "wide_col" (1: keep col_idx as i64 on device),
- * "spmm_algo" (0 streaming row panels, 2 plain wavefront-per-row), "sort_algo"
+ * "spmm_algo" (0 streaming row panels with banded long-row tiles on the matrix cores,
+ * 2 plain wavefront-per-row, 3 streaming row panels without the matrix cores), "sort_algo"
  * (assembly's radix sort: 0 one global histogram + look-back, 1 histogram pass per digit),
  * "spmv_reorder" (hot-column renumbering for gather-bound SpMV: 0 decided per record, 1 whenever the
- * record is large enough, -1 never).
+ * record is large enough, -1 never), "spmv_cblk" (column-blocked copy for wide records with flat column
+ * popularity: 0 decided per record, W > 0 always, with W columns per block, -1 never).  The per-record
+ * choices are made at a record's first product.
  * Returns non-zero for an unknown key. */
 int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, int64_t value);
 int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *key);
