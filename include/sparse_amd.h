@@ -253,7 +253,15 @@ SPARSE_AMD_DECL_ARRAY_2D(f64, double)
                                         struct futhark_opaque_csr_##TT **out0, const int64_t n,   \
                                         const int64_t m, const struct futhark_i64_1d *row_off,    \
                                         const struct futhark_i64_1d *col_idx,                     \
-                                        const struct futhark_##TT##_1d *vals);
+                                        const struct futhark_##TT##_1d *vals);               \
+  /* sr.smvm (:134-146) into caller-owned storage, for loops that must not create an array per */ \
+  /* product (the row-sharded multi-GPU step).  rows == NULL: y[i] = (A x)[i], y has A's n      */ \
+  /* elements.  rows != NULL (n distinct indices into y): y[rows[i]] += (A x)[i] -- how a rank  */ \
+  /* adds the part of its rows that multiplies x entries received from other ranks.             */ \
+  int sparse_amd_csr_##TT##_smvm_into(struct futhark_context *ctx, struct futhark_##TT##_1d *y,   \
+                                      const struct futhark_opaque_csr_##TT *a,                    \
+                                      const struct futhark_##TT##_1d *x,                          \
+                                      const struct futhark_i64_1d *rows);
 
 SPARSE_AMD_DECL_MATRIX(f64, double)
 SPARSE_AMD_DECL_MATRIX(f32, float)

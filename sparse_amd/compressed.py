@@ -348,6 +348,17 @@ class _SR(_Module):
         self.ctx.check(self._f("smvm")(self.ctx.h, ctypes.byref(out), self._chk(A), v.h))
         return self.ctx._out(out, self.t)
 
+    def smvm_into(self, y, A, v, rows=None):
+        """sr.smvm into caller-owned storage (sparse_amd_csr_*_smvm_into): y = A v, or with `rows`
+        (distinct indices into y, one per row of A) y[rows[i]] += (A v)[i].  Pass DeviceArray
+        objects made once with Context.array to keep the per-call host cost to one C call."""
+        y = self.ctx.array(y, self.t)
+        v = self.ctx.array(v, self.t)
+        rows = self.ctx.array(rows, "i64") if rows is not None else None
+        f = getattr(self.ctx.L, "sparse_amd_csr_%s_smvm_into" % self.t)
+        self.ctx.check(f(self.ctx.h, y.h, self._chk(A), v.h, rows.h if rows is not None else None))
+        return y
+
     def smm(self, A, B):
         """Sparse x dense panel, C[:,j] = smvm A B[:,j] (build-defined; see include/sparse_amd.h)."""
         B = self.ctx.array(B, self.t, 2)

@@ -235,6 +235,37 @@ int e_smvm(futhark_context *ctx, VA **out, const H *a, const VA *x) {
   return 0;
 }
 
+// y[rows[i]] += part[i]; rows are distinct (the caller's contract), so no atomics
+template <class T>
+__global__ __launch_bounds__(kBlock) void rows_add_kernel(const T *__restrict__ part, const int64_t *__restrict__ rows,
+                                                          int64_t count, int64_t ylen, T *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const int64_t r = rows[i];
+  if (r >= 0 && r < ylen) y[r] = (T)(y[r] + part[i]);
+}
+
+template <class T, class H, class VA>
+int e_smvm_into(futhark_context *ctx, VA *y, const H *a, const VA *x, const futhark_i64_1d *rows) {
+  if (x->shape[0] != a->b->m) return set_error(ctx, "smvm_into: vector length %lld does not match matrix (%lld)",
+                                               (long long)x->shape[0], (long long)a->b->m);
+  if (!rows) {
+    if (y->shape[0] != a->b->n) return set_error(ctx, "smvm_into: result has %lld elements, matrix has %lld rows",
+                                                 (long long)y->shape[0], (long long)a->b->n);
+    return spmv<T>(ctx, a->b, x->data, y->data);
+  }
+  if (rows->shape[0] != a->b->n) return set_error(ctx, "smvm_into: %lld row indices for %lld rows",
+                                                  (long long)rows->shape[0], (long long)a->b->n);
+  if (a->b->n == 0) return 0;
+  Tmp<T> part(ctx);
+  SAMD_TRY(part.get(a->b->n));
+  SAMD_TRY(spmv<T>(ctx, a->b, x->data, part.p));
+  hipLaunchKernelGGL((rows_add_kernel<T>), dim3((unsigned)cdiv(a->b->n, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     (const T *)part.p, (const int64_t *)rows->data, a->b->n, y->shape[0], y->data);
+  SAMD_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
 template <class T, class H, class A2>
 int e_smm(futhark_context *ctx, A2 **out, const H *a, const A2 *B) {
   if (B->shape[0] != a->b->m) return set_error(ctx, "smm: panel has %lld rows, matrix has %lld columns",
@@ -773,6 +804,10 @@ SAMD_ARRAY_2D(f64, double)
                                         I64A *row_off, I64A *col_idx, const A1(TT) * vals) {                  \
     ENTER(ctx);                                                                                             \
     return e_from_fields<CT>(ctx, out0, n, m, row_off, col_idx, vals);                                        \
+  }                                                                                                           \
+  int sparse_amd_csr_##TT##_smvm_into(CTX, A1(TT) * y, const CSR(TT) * a, const A1(TT) * x, I64A *rows) {     \
+    ENTER(ctx);                                                                                             \
+    return e_smvm_into<CT>(ctx, y, a, x, rows);                                                               \
   }
 
 SAMD_MATRIX(f64, double)

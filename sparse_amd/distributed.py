@@ -171,6 +171,7 @@ class ExchangePlan:
             torch.empty(0, dtype=torch.int64, device=device)
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_own)
         self._sendbuf = None
+        self._ops_key = None
 
     # -- column numbering of the local matrix
     def remap_cols(self, cols):
@@ -211,23 +212,31 @@ class ExchangePlan:
         return x_ext
 
     def exchange_start(self, x_ext):
-        """halo mode: pack and post the point-to-point transfers; returns the work handles."""
-        dist = self.dist
-        own = x_ext[:self.n_own]
-        sendbuf = own[self.send_idx]
-        self._sendbuf = sendbuf                         # keep alive until the sends complete
-        recv = x_ext[self.n_own:]
-        ops, so, ro = [], 0, 0
-        for p in range(self.world):
-            sc, rc = self.send_counts[p], self.recv_counts[p]
-            if p != self.rank:
-                if sc:
-                    ops.append(dist.P2POp(dist.isend, sendbuf[so:so + sc], p))
-                if rc:
-                    ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], p))
-            so += sc
-            ro += rc
-        return dist.batch_isend_irecv(ops) if ops else []
+        """halo mode: pack and post the point-to-point transfers; returns the work handles.
+        The pack buffer and the list of transfers are made at the first call for a given x_ext and
+        reused (the views they hold stay valid: x_ext is persistent)."""
+        torch, dist = self.torch, self.dist
+        key = (x_ext.data_ptr(), x_ext.dtype, tuple(x_ext.shape))
+        if getattr(self, "_ops_key", None) != key:
+            own = x_ext[:self.n_own]
+            self._own = own
+            self._sendbuf = torch.empty((int(self.send_idx.numel()),) + tuple(x_ext.shape[1:]), dtype=x_ext.dtype,
+                                        device=x_ext.device)
+            recv = x_ext[self.n_own:]
+            ops, so, ro = [], 0, 0
+            for p in range(self.world):
+                sc, rc = self.send_counts[p], self.recv_counts[p]
+                if p != self.rank:
+                    if sc:
+                        ops.append(dist.P2POp(dist.isend, self._sendbuf[so:so + sc], p))
+                    if rc:
+                        ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], p))
+                so += sc
+                ro += rc
+            self._ops, self._ops_key = ops, key
+        if self._sendbuf.numel():
+            torch.index_select(self._own, 0, self.send_idx, out=self._sendbuf)
+        return dist.batch_isend_irecv(self._ops) if self._ops else []
 
 
 class DistCsr:
@@ -248,6 +257,15 @@ class DistCsr:
         self.x_ext, self.x_own = plan.new_x(torch_dtype)
         self.x_ghost = self.x_ext[plan.n_own:] if A_gh is not None else None
         self.nnz = A.stored_dims()[2] + (A_gh.stored_dims()[2] if A_gh is not None else 0)
+        # per-step state made once: the result vector and the library's handles on the torch storage
+        # (one C call per product, no array created in the loop)
+        import torch
+        ctx = M.ctx
+        self.y = torch.zeros(n_loc, dtype=torch_dtype, device=self.x_ext.device)
+        self._y_h = ctx.array(self.y, M.t)
+        self._x_h = ctx.array(self.x_own if A_gh is not None else self.x_ext, M.t)
+        self._xg_h = ctx.array(self.x_ghost, M.t) if A_gh is not None and self.x_ghost.numel() else None
+        self._rows_h = ctx.array(self.rows_g, "i64") if rows_g is not None and rows_g.numel() else None
 
     @classmethod
     def from_local_coo(cls, M, dist, n_glob, m_glob, row_lo, row_hi, rs, cs, vs, force_mode=None, split=True):
@@ -315,27 +333,29 @@ class DistCsr:
         return self.plan.exchange(self.x_ext)
 
     def local_smvm(self, x_ext=None):
-        """The dominant kernel alone: this rank's rows against data already in place."""
-        if self.A_gh is not None:
-            return self.M.sr.smvm(self.A, self.x_own)
-        return self.M.sr.smvm(self.A, self.x_ext if x_ext is None else x_ext)
+        """The dominant kernel alone: this rank's rows against data already in place.  Returns the
+        persistent result vector DistCsr.y (torch tensor, overwritten by the next product)."""
+        if x_ext is not None and x_ext.data_ptr() != self.x_ext.data_ptr():
+            self.x_ext.copy_(x_ext)
+        self.M.sr.smvm_into(self._y_h, self.A, self._x_h)
+        return self.y
 
     def smvm(self, x_own=None):
         """y[rows of this rank] = A[rows,:] x.  x_own: this rank's slice of x (ideally the
-        view DistCsr.x_own itself, then nothing is copied)."""
+        view DistCsr.x_own itself, then nothing is copied).  Returns DistCsr.y (overwritten by the
+        next product)."""
         if self.A_gh is None:
-            return self.local_smvm(self.exchange(x_own))
-        import torch
+            self.exchange(x_own)
+            return self.local_smvm()
         if x_own is not None and x_own.data_ptr() != self.x_own.data_ptr():
             self.x_own.copy_(x_own)
         works = self.plan.exchange_start(self.x_ext)       # halo entries go on the wire ...
-        y = self.M.sr.smvm(self.A, self.x_own)             # ... while the owned columns are multiplied
+        self.M.sr.smvm_into(self._y_h, self.A, self._x_h)  # ... while the owned columns are multiplied
         for w in works:
             w.wait()
-        if self.rows_g.numel():
-            yg = self.M.sr.smvm(self.A_gh, self.x_ghost)
-            torch.as_tensor(y, device=self.x_ext.device).index_add_(0, self.rows_g, torch.as_tensor(yg, device=self.x_ext.device))
-        return y
+        if self._rows_h is not None:
+            self.M.sr.smvm_into(self._y_h, self.A_gh, self._xg_h, self._rows_h)
+        return self.y
 
     def smm(self, B_own):
         """C[rows of this rank][k] = A[rows,:] B for a dense B whose rows are partitioned

@@ -60,7 +60,7 @@ def main():
         D = DistCsr.from_coo_chunks(M, dist, n, n, t(chunk(r), dev), t(chunk(c), dev), t(chunk(v), dev),
                                     force_mode=mode)
         lo, hi = D.bounds[rank], D.bounds[rank + 1]
-        y = np.asarray(D.smvm(t(x[lo:hi], dev)))
+        y = D.smvm(t(x[lo:hi], dev)).cpu().numpy()
         assert np.array_equal(y, y_ref[lo:hi]), ("smvm", mode)
         C = np.asarray(D.smm(t(B[lo:hi], dev)))
         assert np.array_equal(C, C_ref[lo:hi]), ("smm", mode)
@@ -78,7 +78,7 @@ def main():
     assert D2.mode == "halo" and D2.A_gh is not None
     lo, hi = D2.bounds[rank], D2.bounds[rank + 1]
     for rep in range(3):
-        y = np.asarray(D2.smvm(t((rep + 1) * x2[lo:hi], dev)))
+        y = D2.smvm(t((rep + 1) * x2[lo:hi], dev)).cpu().numpy()
         assert np.array_equal(y, (rep + 1) * y2[lo:hi]), ("banded smvm", rep)
     dist.barrier()
     if rank == 0:

@@ -344,6 +344,34 @@ def test_smvm_empty_and_shape_errors(ctx):
         M.sr.smvm(Z, np.ones(4))
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+def test_smvm_into_caller_storage(ctx, dtype):
+    """sparse_amd_csr_*_smvm_into: same bits as the allocating entry; with row indices it adds
+    into the named elements only."""
+    from sparse_amd.compressed import SparseError
+    M = mk(ctx, dtype)
+    n, m = 3000, 2500
+    r, c, v = random_coo(n, m, 40000, dtype, seed=21)
+    A = M.sr.sparse(n, m, (r, c, v))
+    x = synth.uniform_values(3, m, dtype)
+    want = M.sr.smvm(A, x).numpy()
+    y = ctx.array(np.full(n, 7, NP[dtype]), dtype)
+    M.sr.smvm_into(y, A, x)
+    assert np.array_equal(y.numpy(), want)
+    # y[rows[i]] += (A x)[i] into a longer vector
+    base = synth.uniform_values(4, 2 * n, dtype)
+    rows = np.random.default_rng(5).permutation(2 * n)[:n].astype(np.int64)
+    big = ctx.array(base.copy(), dtype)
+    M.sr.smvm_into(big, A, x, rows)
+    expect = base.copy()
+    expect[rows] = (expect[rows] + want).astype(NP[dtype])
+    assert np.array_equal(big.numpy(), expect)
+    with pytest.raises(SparseError):
+        M.sr.smvm_into(ctx.array(np.zeros(n + 1, NP[dtype]), dtype), A, x)
+    with pytest.raises(SparseError):
+        M.sr.smvm_into(big, A, x, rows[:-1])
+
+
 def test_smvm_is_reproducible(ctx):
     M = mk(ctx, "f64")
     r, c, v = skewed_coo(3000, 9000, "f64", 8)
