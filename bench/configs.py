@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--spmm-algo", type=int, default=0)
     ap.add_argument("--cblk", type=int, default=0, help="spmv_cblk option: -1 never, W > 0 force W columns per block")
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--pb", type=int, default=0, help="spmv_pb option: 1 two-pass SpMV for large gather-bound records (opt-in)")
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--compare", action="store_true", help="also time torch.sparse (rocSPARSE) CSR SpMV as a comparator")
     args = ap.parse_args()
@@ -49,6 +50,8 @@ def main():
         ctx.set_option("spmv_algo", args.algo)
     if args.cblk:
         ctx.set_option("spmv_cblk", args.cblk)
+    if args.pb:
+        ctx.set_option("spmv_pb", args.pb)
     if args.spmm_algo:
         ctx.set_option("spmm_algo", args.spmm_algo)
     if args.lanes:

@@ -7,6 +7,7 @@
 #include "radix_sort.hpp"
 #include "assembly.hpp"
 #include "spmv.hpp"
+#include "spmv_pb.hpp"
 #include "spmm.hpp"
 #include "convert.hpp"
 #include "mono.hpp"
@@ -556,6 +557,10 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_cblk")) ctx->opt_spmv_cblk = value;
   else if (!strcmp(key, "sort_algo")) ctx->opt_sort_algo = value;
   else if (!strcmp(key, "spmv_reorder")) ctx->opt_spmv_reorder = value;
+  else if (!strcmp(key, "spmv_pb")) ctx->opt_spmv_pb = value;
+  else if (!strcmp(key, "spmv_pb_rows")) ctx->opt_spmv_pb_rows = value;
+  else if (!strcmp(key, "spmv_pb_lines")) ctx->opt_spmv_pb_lines = value;
+  else if (!strcmp(key, "spmv_pb_entries")) ctx->opt_spmv_pb_entries = value;
   else if (!strcmp(key, "ablate")) ctx->opt_ablate = value;
   else return set_error(ctx, "unknown option '%s'", key);
   return 0;
@@ -569,6 +574,7 @@ int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *k
   if (!strcmp(key, "spmv_cblk")) return ctx->opt_spmv_cblk;
   if (!strcmp(key, "sort_algo")) return ctx->opt_sort_algo;
   if (!strcmp(key, "spmv_reorder")) return ctx->opt_spmv_reorder;
+  if (!strcmp(key, "spmv_pb")) return ctx->opt_spmv_pb;
   if (!strcmp(key, "num_cu")) return ctx->num_cu;
   return -1;
 }

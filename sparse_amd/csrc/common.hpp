@@ -115,6 +115,9 @@ struct futhark_context {
   int64_t opt_spmm_algo = 0;
   int64_t opt_spmv_cblk = 0;  // 0 auto, > 0 always with this many columns per block, -1 never
   int64_t opt_spmv_reorder = 0;  // 0 auto, 1 always (when the record qualifies by size), -1 never
+  int64_t opt_spmv_pb = 0;  // two-pass SpMV (spmv_pb.hpp), opt-in: 0 off, 1 for large gather-bound records, 2 always (tests)
+  int64_t opt_spmv_pb_rows = 0, opt_spmv_pb_lines = 0, opt_spmv_pb_entries = 0;  // test overrides: rows per panel,
+                                                                                 // 32-column lines per block, entries per panel
   int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
   // statistics for futhark_context_report
@@ -246,6 +249,15 @@ struct CsrBody {
   mutable uint16_t *cblk_end = nullptr;       // [panels * nb * rows per panel] end of each row inside its piece
   mutable int32_t *cblk_col = nullptr;        // [nnz] entries in piece order
   mutable T *cblk_val = nullptr;
+  // two-pass copy for gather-bound SpMV on power-law records (spmv_pb.hpp); built lazily
+  mutable int pb_state = 0;  // 0 undecided, 1 active, -1 rejected
+  mutable int64_t pb_np = 0, pb_nb = 0, pb_w = 0, pb_nl = 0;  // panels, column blocks, columns per block, 32-column lines
+  mutable int64_t *pb_panel_row = nullptr;   // [np + 1] first row of every panel
+  mutable int64_t *pb_piece_ptr = nullptr;   // [np * nb + 1] start of every piece, panel-major
+  mutable uint32_t *pb_line_of_rank = nullptr;  // [nl] lines by descending entry count
+  mutable uint16_t *pb_col16 = nullptr, *pb_row16 = nullptr;  // [nnz] column inside the block, row inside the panel
+  mutable T *pb_val = nullptr, *pb_prod = nullptr;            // [nnz] values in piece order; products (rewritten per call)
+  mutable T *pb_x = nullptr;                                  // [nb * w] x in block order (rewritten per call)
   // SpMM: tiles that go to the matrix cores (spmm.hpp), decided at the first product
   mutable int32_t *tile_split = nullptr;  // [ntiles] ids of the dense-block tiles, then of the others
   mutable int64_t n_mfma_tiles = -1;
@@ -270,6 +282,14 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->cblk_end);
   dfree(ctx, b->cblk_col);
   dfree(ctx, b->cblk_val);
+  dfree(ctx, b->pb_panel_row);
+  dfree(ctx, b->pb_piece_ptr);
+  dfree(ctx, b->pb_line_of_rank);
+  dfree(ctx, b->pb_col16);
+  dfree(ctx, b->pb_row16);
+  dfree(ctx, b->pb_val);
+  dfree(ctx, b->pb_prod);
+  dfree(ctx, b->pb_x);
   delete b;
 }
 

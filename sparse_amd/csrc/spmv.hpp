@@ -668,6 +668,12 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
   return 0;
 }
 
+// two-pass path for gather-bound power-law records (spmv_pb.hpp)
+template <class T>
+int pb_prepare(futhark_context *ctx, const CsrBody<T> *a);
+template <class T>
+int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y);
+
 // y[n] = A[n][m] x[m].  x and y are device pointers of the right lengths.
 template <class T>
 int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
@@ -677,6 +683,8 @@ int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
     return 0;
   }
   const int64_t algo = ctx->opt_spmv_algo;
+  if ((algo == 0 || algo == 1) && a->pb_state == 0) SAMD_TRY(pb_prepare<T>(ctx, a));
+  if ((algo == 0 || algo == 1) && a->pb_state == 1) return spmv_pb<T>(ctx, a, x, y);
   if ((algo == 0 || algo == 1) && a->reorder_state == 0) SAMD_TRY(reorder_prepare<T>(ctx, a));
   if ((algo == 0 || algo == 1) && a->reorder_state == 1) {
     hipLaunchKernelGGL((reorder_gather_x_kernel<T>), dim3((unsigned)cdiv(a->m, kBlock)), dim3(kBlock), 0, ctx->stream,

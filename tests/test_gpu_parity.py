@@ -304,6 +304,39 @@ def test_smvm_column_blocks(ctx, dtype, width):
         ctx.set_option("spmv_cblk", 0)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+@pytest.mark.parametrize("geom", [(0, 0, 0), (64, 2, 2048), (700, 5, 4096)], ids=["one_piece", "tiny", "mid"])
+def test_smvm_two_pass_panels(ctx, dtype, geom):
+    """spmv_pb=2 forces the two-pass product (opt-in, measured slower than the one-pass path: kept as a record): entries regrouped
+    into (row panel) x (column block) pieces, products streamed out, then added per panel.  The overrides
+    shrink panels and blocks so that small records have many of both.  Against the oracle within the dtype's
+    bar (the summation order differs from the oracle's), i32 exact; a second x on the cached pieces; a very
+    long row (longer than a panel's entry budget), empty rows, runs of them; the record itself untouched."""
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    rows, lines, entries = geom
+    ctx.set_option("spmv_pb", 2)
+    ctx.set_option("spmv_pb_rows", rows)
+    ctx.set_option("spmv_pb_lines", lines)
+    ctx.set_option("spmv_pb_entries", entries)
+    try:
+        for n, m, gen in ((3000, 9000, lambda: skewed_coo(3000, 9000, dtype, 8)),
+                          (20000, 5000, lambda: random_coo(20000, 5000, 90000, dtype, seed=91, dup_frac=0.05)),
+                          (1, 7000, lambda: random_coo(1, 7000, 6000, dtype, seed=93)),
+                          (6000, 1, lambda: random_coo(6000, 1, 900, dtype, seed=94)),
+                          (700, 6000, lambda: tuple(a if i != 1 else a + 1500 for i, a in
+                                                    enumerate(random_coo(700, 4500, 20000, dtype, seed=92))))):
+            r, c, v = gen()
+            A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
+            x = synth.uniform_values(5, m, dtype)
+            close(M.sr.smvm(A, x), O.sr_smvm(Ao, x), dtype)
+            x2 = synth.uniform_values(6, m, dtype)
+            close(M.sr.smvm(A, x2), O.sr_smvm(Ao, x2), dtype)
+            assert_same_record(A, Ao)
+    finally:
+        for k in ("spmv_pb", "spmv_pb_rows", "spmv_pb_lines", "spmv_pb_entries"):
+            ctx.set_option(k, 0)
+
+
 @pytest.mark.parametrize("lanes", [0, 8])
 def test_smvm_long_runs_of_empty_rows(ctx, lanes):
     """Hundreds of thousands of empty rows before, between and after the stored ones: the tile that holds a
