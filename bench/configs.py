@@ -37,8 +37,9 @@ def main():
     ap.add_argument("--spmm-algo", type=int, default=0)
     ap.add_argument("--cblk", type=int, default=0, help="spmv_cblk option: -1 never, W > 0 force W columns per block")
     ap.add_argument("--lanes", type=int, default=0)
-    ap.add_argument("--pb", type=int, default=0, help="spmv_pb option: 1 two-pass SpMV for large gather-bound records (opt-in)")
+    ap.add_argument("--pb", type=int, default=0, help="spmv_pb option: -1 never, 1 also records of flat popularity, 2 always")
     ap.add_argument("--ablate", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="any context option, key=value (kernel lab)")
     ap.add_argument("--compare", action="store_true", help="also time torch.sparse (rocSPARSE) CSR SpMV as a comparator")
     args = ap.parse_args()
     import torch
@@ -58,6 +59,9 @@ def main():
         ctx.set_option("spmv_lanes", args.lanes)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
+    for kv in args.opt:
+        key, val = kv.split("=")
+        ctx.set_option(key, int(val))
 
     def run(name, dtype, n, m, gen, spmm_k=0):
         vb = 8 if dtype == "f64" else 4

@@ -522,8 +522,8 @@ void *sparse_amd_context_get_stream(struct futhark_context *ctx);
  * "spmv_reorder" (hot-column renumbering for gather-bound SpMV: 0 decided per record, 1 whenever the
  * record is large enough, -1 never), "spmv_cblk" (column-blocked copy for wide records with flat column
  * popularity: 0 decided per record, W > 0 always, with W columns per block, -1 never).  "spmv_pb" (two-pass SpMV with the
- * x and y slices in LDS, opt-in: 0 off, 1 for large gather-bound records, 2 always; measured slower than the
- * default on MI355X).  The per-record
+ * x and y slices in LDS: 0 large skewed records of 4-byte values, 1 also flat column popularity, 2 always,
+ * -1 never).  The per-record
  * choices are made at a record's first product.
  * Returns non-zero for an unknown key. */
 int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, int64_t value);

@@ -576,6 +576,7 @@ int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *k
   if (!strcmp(key, "spmv_reorder")) return ctx->opt_spmv_reorder;
   if (!strcmp(key, "spmv_pb")) return ctx->opt_spmv_pb;
   if (!strcmp(key, "num_cu")) return ctx->num_cu;
+  if (!strcmp(key, "spmv_last_path")) return ctx->last_spmv_path;
   return -1;
 }
 const char *sparse_amd_version(void) { return "sparse_amd 0.1 (gfx950)"; }

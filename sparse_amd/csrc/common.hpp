@@ -115,13 +115,14 @@ struct futhark_context {
   int64_t opt_spmm_algo = 0;
   int64_t opt_spmv_cblk = 0;  // 0 auto, > 0 always with this many columns per block, -1 never
   int64_t opt_spmv_reorder = 0;  // 0 auto, 1 always (when the record qualifies by size), -1 never
-  int64_t opt_spmv_pb = 0;  // two-pass SpMV (spmv_pb.hpp), opt-in: 0 off, 1 for large gather-bound records, 2 always (tests)
+  int64_t opt_spmv_pb = 0;  // two-pass SpMV (spmv_pb.hpp), 0 large skewed gather-bound records of 4-byte values, 1 also flat popularity, 2 always (tests), -1 never
   int64_t opt_spmv_pb_rows = 0, opt_spmv_pb_lines = 0, opt_spmv_pb_entries = 0;  // test overrides: rows per panel,
                                                                                  // 32-column lines per block, entries per panel
   int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
   // statistics for futhark_context_report
   int64_t n_entries = 0;
+  int64_t last_spmv_path = 0;  // 0 one-pass, 1 hot-column renumbering, 2 column blocks, 3 two passes (tests read it back)
 };
 
 namespace samd {

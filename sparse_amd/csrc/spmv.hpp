@@ -345,6 +345,12 @@ __global__ __launch_bounds__(kBlock) void reorder_gather_x_kernel(const T *__res
   if (r < m) x_hot[r] = x[perm[r]];
 }
 
+// two-pass path for gather-bound power-law records (spmv_pb.hpp)
+template <class T>
+int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted);
+template <class T>
+int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y);
+
 // Decides and, if worthwhile, builds the renumbering.  One-time host synchronisations (two small reads).
 template <class T>
 int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
@@ -398,6 +404,12 @@ int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
   if (read_small(ctx, ctx->d_small, 3, h2) != 0) { dfree(ctx, hot_perm); return 1; }
   if ((int)(h2[2] & 0xffffffff) != 0) { dfree(ctx, hot_perm); return set_error(ctx, "internal: radix sort look-back timed out"); }
   if (!force && h2[0] * 2 < a->nnz) { dfree(ctx, hot_perm); a->gather_flat = true; return 0; }  // flat popularity: nothing to pack
+  // Large, wide, skewed: for 4-byte values the two-pass product with the x and y slices in LDS is faster than any
+  // renumbering (C3: 1.65 against 2.08 ms) -- if the record qualifies it takes over and nothing more is built here.
+  if (!force && a->pb_state == 0) {
+    if (pb_prepare<T>(ctx, a, true) != 0) { dfree(ctx, hot_perm); return 1; }
+    if (a->pb_state == 1) { dfree(ctx, hot_perm); return 0; }
+  }
   int32_t *col_hot = nullptr;
   T *x_hot = nullptr;
   if (dalloc(ctx, &col_hot, a->nnz) != 0 || dalloc(ctx, &x_hot, a->m) != 0) {
@@ -668,12 +680,6 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
   return 0;
 }
 
-// two-pass path for gather-bound power-law records (spmv_pb.hpp)
-template <class T>
-int pb_prepare(futhark_context *ctx, const CsrBody<T> *a);
-template <class T>
-int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y);
-
 // y[n] = A[n][m] x[m].  x and y are device pointers of the right lengths.
 template <class T>
 int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
@@ -683,10 +689,13 @@ int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
     return 0;
   }
   const int64_t algo = ctx->opt_spmv_algo;
-  if ((algo == 0 || algo == 1) && a->pb_state == 0) SAMD_TRY(pb_prepare<T>(ctx, a));
-  if ((algo == 0 || algo == 1) && a->pb_state == 1) return spmv_pb<T>(ctx, a, x, y);
-  if ((algo == 0 || algo == 1) && a->reorder_state == 0) SAMD_TRY(reorder_prepare<T>(ctx, a));
+  if ((algo == 0 || algo == 1) && a->pb_state == 0 && ctx->opt_spmv_pb > 0) SAMD_TRY(pb_prepare<T>(ctx, a, false));
+  if ((algo == 0 || algo == 1) && a->pb_state == 1) { ctx->last_spmv_path = 3; return spmv_pb<T>(ctx, a, x, y); }
+  if ((algo == 0 || algo == 1) && a->reorder_state == 0) SAMD_TRY(reorder_prepare<T>(ctx, a));  // may choose the two-pass path
+  if ((algo == 0 || algo == 1) && a->pb_state == 1) { ctx->last_spmv_path = 3; return spmv_pb<T>(ctx, a, x, y); }
+  ctx->last_spmv_path = 0;
   if ((algo == 0 || algo == 1) && a->reorder_state == 1) {
+    ctx->last_spmv_path = 1;
     hipLaunchKernelGGL((reorder_gather_x_kernel<T>), dim3((unsigned)cdiv(a->m, kBlock)), dim3(kBlock), 0, ctx->stream,
                        x, (const uint32_t *)a->hot_perm, a->m, a->x_hot);
     SAMD_LAUNCH_CHECK(ctx);
@@ -694,6 +703,7 @@ int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
   }
   if ((algo == 0 || algo == 1) && a->reorder_state == -1 && a->cblk_state == 0) SAMD_TRY(cblk_prepare<T>(ctx, a));
   if ((algo == 0 || algo == 1) && a->cblk_state == 1) {
+    ctx->last_spmv_path = 2;
     const int64_t panels = cdiv(a->n, kCblkRows);
     for (int64_t b = 0; b < a->cblk_nb; b++) {
       hipLaunchKernelGGL((spmv_cblk_kernel<T>), dim3((unsigned)panels), dim3(kBlock), 0, ctx->stream,

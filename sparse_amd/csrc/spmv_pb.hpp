@@ -1,33 +1,39 @@
 // spmv_pb.hpp -- two-pass SpMV for gather-bound records (power-law graphs: BASELINE configs[2]).
-// OPT-IN ("spmv_pb" = 1): measured slower than the one-pass path on MI355X, kept with its tests as the record
-// of the experiment.
 //
 // On an RMAT matrix the one-pass kernel (spmv.hpp) is bound by the rate at which a CU turns over x
 // gathers that miss its L1 (~140-150 G gathers/s chip-wide, measured with every gather hitting L2), not by
 // HBM: 3e8 entries cost 2 ms where their bytes would stream in 0.35 ms.  Here no gather leaves the CU.
 // At its first product such a record gets a second copy of its entries cut into PIECES = (row panel) x
-// (column block), a panel being <= R consecutive rows holding <= ~E entries and a block W columns, R and W
-// sized so that a slice of y, or of x, is 128 KB of LDS.  A product is then
-//   pass 1  (workgroup = column block, its slice of x in LDS): every entry's product val * x[col], the gather
-//           served by LDS, streamed out in piece order;
-//   pass 2  (workgroup = row panel, its slice of y in LDS): the products of the panel, contiguous, added
-//           into the slice by LDS atomics (runs of equal rows are first folded inside the wavefront), then the
-//           slice is written to y.
-// Entries are laid out [panel][block][row][column], so pass 2 streams one contiguous range and pass 1 walks
-// one piece per panel.  Columns are dealt to blocks by popularity (32-column lines ranked by entry count,
-// line of rank q -> block q mod NB): every block, hence every piece, holds about the same number of entries
-// whatever the skew, and x is brought into that order once per product by copying whole lines.
-// Bytes per entry: 4+2 read, 4 written (pass 1), 4+2 read (pass 2) = 16 against 8 algorithmic (f32), all of
-// it streaming.  The sum of a row is formed in piece order by atomics, so it is NOT the oracle's left-to-right
-// order and not bit-reproducible run to run for floating point (within the 1e-5 / 1e-12 bars; exact for i32).
+// (column block): a panel is <= R consecutive rows holding <= ~E entries, a block is W columns, R and W sized so
+// that a slice of y (f64 accumulators), or of x, is 128 KB of LDS.  A product is then
+//   pass 0  x copied into block order (whole 32-column lines);
+//   pass 1  (workgroup = share of one column block, its slice of x in LDS): every entry's product val * x[col],
+//           the gather served by LDS; the block's entries are ONE contiguous range, read and written as a stream;
+//   pass 2  (workgroup = row panel, its slice of y in LDS): each wavefront walks pieces (panel, block) of the
+//           panel, adds their products into the slice by LDS atomics (runs of equal rows folded inside the
+//           wavefront first), then the slice is written to y.
+// Entries are laid out [block][panel][row][column].  Columns are dealt to blocks by popularity (32-column lines
+// ranked by sampled entry count, line of rank q -> block q mod NB): every block, hence every piece, holds about
+// the same number of entries whatever the skew.
+// Bytes per entry: 4+2 read, 4 written (pass 1), 4+2 read (pass 2) = 16 against 8 algorithmic (f32).
+// The slice of y is accumulated in f64 (i32: in i32), so the sum of a row does not follow the oracle's
+// left-to-right f32 order: within the 1e-5 bar (in fact closer to the exact sum), exact for i32.
 //
-// Measured on C3 (RMAT scale 24, f32, 2.96e8 entries; rocprofv3 kernel stats, gpurun_out/pb_lab_*): x into block
-// order 0.04 ms, pass 1 0.80 ms (0.55 without the product store: walking ~540-entry pieces is latency-bound),
-// pass 2 1.99 ms of which 0.47 is the streaming and 1.5 the LDS accumulation -- ds_add_f32 retires about one
-// lane every 3-4 cycles per CU, with or without the in-wavefront fold (2.35 ms with plain atomics).  Total
-// 2.8 ms against 2.08 ms for the one-pass kernel with hot-column renumbering.  What would have to change: pass 2
-// without LDS atomics (each wavefront owning a row range of the panel and walking its ~34-entry fragment of
-// every piece with plain read-modify-writes), estimated 0.7 ms issue-bound, i.e. ~1.5 ms in all: not built.
+// What the hardware taught (C3 = RMAT scale 24, f32, 2.96e8 entries; rocprofv3 kernel stats via bench/pb_lab.sh,
+// LDS rates via bench/lds_lab.hip):
+//   * ds_add_f32 retires one lane every 3.0 cycles per CU, ds_add_f64 and ds_add_u32 one every 0.4 (same
+//     address: 3-4 cycles each for all).  With an f32 slice pass 2 took 1.99 ms, with f64 accumulators 0.85-0.95.
+//   * a load behind a branch (`ok ? load : 0`) makes the compiler wait for it at once: the predicated form of
+//     pass 1 streamed at 2 TB/s (0.87 ms without its store), the clamped-address form at 4.7 TB/s (0.38 ms).
+//   * stores that straddle 128-byte lines: pass 1 0.91 ms, the same loop started on a 32-entry boundary 0.67 ms
+//     (4.5 TB/s for 1.8 GB read + 1.2 GB written); non-temporal or plain stores make no difference.
+//   * walking pieces costs: with the layout [panel][block] (pass 1 walks ~300-entry pieces and writes them, pass 2
+//     streams) pass 1 took 1.1-1.4 ms; entries per panel E = 1 M / 512 K / 256 K / 128 K / 64 K give pass 2
+//     1.22 / 0.96 / 0.94 / 0.99 / 1.27 ms (heavy panels are slow per entry, small pieces are slow per piece).
+//   * shipped: 0.06 + 0.66 + 0.94 = 1.66 ms per product against 2.08 ms for the one-pass kernel with hot-column
+//     renumbering (19.8 % of HBM peak on the algorithmic bytes against 15.9 %).  One-off set-up 40 ms.
+// Default for large, wide, skewed records of 4-byte values (reorder_prepare hands them over); 8-byte values stay
+// on the one-pass paths (28 B per entry here against 12).
 #pragma once
 
 #include <vector>
@@ -40,13 +46,17 @@ constexpr int kPbThreads = 1024;  // one workgroup per CU: the slice takes most 
 constexpr int kPbWaves = kPbThreads / 64;
 constexpr int kPbLine = 32;                         // columns per line (the unit dealt to blocks)
 constexpr int kPbSliceBytes = 128 << 10;            // slice of x (pass 1) or y (pass 2) in LDS
-constexpr int64_t kPbPanelEntries = 512 << 10;      // a panel is closed once it holds this many entries
-constexpr int64_t kPbMinPiece = 192;                // auto mode: mean entries per piece below this -> not worth it
+constexpr int64_t kPbPanelEntries = 256 << 10;      // a panel is closed once it holds this many entries (measured on C3:
+                                                    // 1 M 1.22 ms, 512 K 0.96, 256 K 0.94, 128 K 0.99, 64 K 1.27 in pass 2)
+constexpr int64_t kPbMinPiece = 128;               // auto mode: mean entries per piece below this -> not worth it
 
+// Popularity of the 32-column lines from every stride-th entry: the ranking only has to deal the lines to the
+// blocks evenly, and counting all 3e8 entries of C3 took 42 ms of atomics on the hottest counters.
 __global__ __launch_bounds__(kBlock) void pb_line_count_kernel(const int32_t *__restrict__ col, int64_t nnz,
-                                                               uint32_t *__restrict__ counts) {
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * kBlock)
-    atomicAdd(&counts[col[e] / kPbLine], 1u);
+                                                               int64_t stride, uint32_t *__restrict__ counts) {
+  const int64_t samples = (nnz + stride - 1) / stride;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < samples; i += (int64_t)gridDim.x * kBlock)
+    atomicAdd(&counts[col[i * stride] / kPbLine], 1u);
 }
 
 __global__ __launch_bounds__(kBlock) void pb_rank_kernel(const uint32_t *__restrict__ line_of_rank, int64_t nl,
@@ -55,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void pb_rank_kernel(const uint32_t *__restr
   if (q < nl) rank_of_line[line_of_rank[q]] = (uint32_t)q;
 }
 
-// key of entry e = panel * nb + block
+// key of entry e = block * np + panel (block-major: pass 1 streams a block's entries as one range)
 __global__ __launch_bounds__(kBlock) void pb_key_kernel(const int64_t *__restrict__ row_ptr,
                                                         const int32_t *__restrict__ col, int64_t nnz,
                                                         const int64_t *__restrict__ tile_lb, int64_t tile,
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void pb_key_kernel(const int64_t *__restric
     if (panel_row[mid] <= r) lo = mid; else hi = mid;
   }
   const int64_t q = rank_of_line[col[e] / kPbLine];
-  keys[e] = (uint32_t)(lo * nb + q % nb);
+  keys[e] = (uint32_t)((q % nb) * np + lo);
 }
 
 // piece_ptr[k] = first position whose key is >= k, k = 0 .. pieces
@@ -93,14 +103,14 @@ __global__ __launch_bounds__(kBlock) void pb_build_kernel(const int64_t *__restr
                                                           int64_t nnz, const int64_t *__restrict__ tile_lb,
                                                           int64_t tile, const int64_t *__restrict__ panel_row,
                                                           const uint32_t *__restrict__ rank_of_line, int64_t nb,
-                                                          const uint32_t *__restrict__ sorted_keys,
+                                                          int64_t np, const uint32_t *__restrict__ sorted_keys,
                                                           const uint32_t *__restrict__ perm,
                                                           uint16_t *__restrict__ col16, uint16_t *__restrict__ row16,
                                                           T *__restrict__ pval) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nnz) return;
   const int64_t src = perm ? (int64_t)perm[i] : i;  // no sort pass ran (one piece): identity
-  const int64_t p = (int64_t)sorted_keys[i] / nb;
+  const int64_t p = (int64_t)sorted_keys[i] % np;
   const int64_t r = find_row(row_ptr, tile_lb, tile, src);
   const int32_t c = col[src];
   const int64_t q = rank_of_line[c / kPbLine];
@@ -121,12 +131,20 @@ __global__ __launch_bounds__(kBlock) void pb_xperm_kernel(const T *__restrict__ 
   xperm[(q % nb) * w + (q / nb) * kPbLine + j] = c < m ? x[c] : (T)0;
 }
 
+__device__ __forceinline__ int64_t cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// value of lane src, the same in every lane and known to be so (scalar registers)
+__device__ __forceinline__ int64_t pb_bcast64(int64_t v, int src) {
+  const int lo = __builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)v, src, 64));
+  const int hi = __builtin_amdgcn_readfirstlane(__shfl((int)(uint32_t)((uint64_t)v >> 32), src, 64));
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 template <class T, int U>
 __global__ __launch_bounds__(kPbThreads) void pb_pass1_kernel(const int64_t *__restrict__ piece_ptr,
                                                               const uint16_t *__restrict__ col16,
                                                               const T *__restrict__ pval, const T *__restrict__ xperm,
-                                                              T *__restrict__ prod, int64_t np, int64_t nb, int w,
-                                                              int lab) {
+                                                              T *__restrict__ prod, int64_t np, int w, int lab) {
   __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
   const int64_t b = blockIdx.x;
   {
@@ -134,48 +152,60 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1_kernel(const int64_t *__r
     const raw16 *src = reinterpret_cast<const raw16 *>(xperm + b * (int64_t)w);
     for (int j = threadIdx.x; j < w / PER; j += kPbThreads) reinterpret_cast<raw16 *>(xs)[j] = src[j];
   }
+  // the block's entries are one contiguous range; the gridDim.y workgroups of a block take equal shares of it
+  constexpr int64_t kStep = (int64_t)kPbThreads * U;
+  const int64_t s0 = piece_ptr[b * np], e0 = piece_ptr[(b + 1) * np];
+  const int64_t per = cdiv_dev(cdiv_dev(e0 - s0, kStep), (int64_t)gridDim.y) * kStep;
+  const int64_t s = s0 + (int64_t)blockIdx.y * per;
+  const int64_t e = s + per < e0 ? s + per : e0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t stride = (int64_t)gridDim.y * kPbWaves;
-  int64_t p = (int64_t)blockIdx.y * kPbWaves + wave;
-  int64_t s = 0, e = 0;
-  if (p < np) { s = piece_ptr[p * nb + b]; e = piece_ptr[p * nb + b + 1]; }
-  while (p < np) {
-    const int64_t pn = p + stride;
-    int64_t sn = 0, en = 0;
-    if (pn < np) { sn = piece_ptr[pn * nb + b]; en = piece_ptr[pn * nb + b + 1]; }  // in flight during this piece
-    for (int64_t i = s + lane; i < e; i += 64 * U) {
-      uint16_t c[U];
-      T v[U];
+  // Loads are never predicated: a load behind a branch makes the compiler wait for it at once (measured: the
+  // predicated form of this loop ran at 2 TB/s).  Partial steps clamp their addresses instead.  Steps start at
+  // a multiple of 32 entries so that every wavefront store covers whole 128-byte lines.
+  const int64_t abase = s & ~(int64_t)31;
+  for (int64_t i0 = abase; i0 < e; i0 += kStep) {
+    const bool full = i0 >= s && i0 + kStep <= e;  // uniform
+    uint16_t c[U];
+    T v[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int64_t ii = i + 64 * u;
-        const bool ok = ii < e;
-        c[u] = ok ? ntload(&col16[ii]) : (uint16_t)0;
-        v[u] = ok ? ntload(&pval[ii]) : (T)0;
-      }
+    for (int u = 0; u < U; u++) {
+      const int64_t ii = i0 + (int64_t)u * kPbThreads + threadIdx.x;
+      const int64_t ic = full ? ii : (ii < s ? s : (ii < e ? ii : e - 1));
+      c[u] = ntload(&col16[ic]);
+      v[u] = ntload(&pval[ic]);
+    }
+    T pr[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int64_t ii = i + 64 * u;
-        if (ii < e) {
-          const T pr = lab == 2 ? v[u] : (T)(v[u] * xs[c[u]]);  // lab 2: no LDS gather
-          if (lab != 1 || pr == (T)12345) __builtin_nontemporal_store(pr, &prod[ii]);  // lab 1: no store
-        }
+    for (int u = 0; u < U; u++) pr[u] = lab == 2 ? v[u] : (T)(v[u] * xs[c[u]]);  // lab 2: no LDS gather
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t ii = i0 + (int64_t)u * kPbThreads + threadIdx.x;
+      if (full || (ii >= s && ii < e)) {
+        if (lab == 3) prod[ii] = pr[u];                                                      // lab 3: plain store
+        else if (lab != 1 || pr[u] == (T)12345) __builtin_nontemporal_store(pr[u], &prod[ii]);  // lab 1: no store
       }
     }
-    p = pn; s = sn; e = en;
   }
 }
 
 // Adds v into ys[row] for the lanes of one wavefront whose rows come in runs (entries of a piece are sorted by
 // row): a run is folded inside the wavefront and only its last lane touches LDS, so a heavy row costs one
 // atomic per 64 entries instead of 64 colliding ones.  row < 0: lane holds nothing.
+// The slice of y is accumulated in Acc<T>: double for float as well -- measured (bench/lds_lab.hip) ds_add_f32
+// retires one lane every 3.0 cycles per CU, ds_add_f64 and ds_add_u32 one every 0.4 -- which also makes the sum
+// of a float row insensitive to the order the atomics land in.
+template <class T> struct PbAcc { typedef double type; };
+template <> struct PbAcc<int32_t> { typedef int32_t type; };
+
 template <class T>
-__device__ __forceinline__ void pb_seg_add(T *ys, int row, T v, int lane) {
+__device__ __forceinline__ void pb_seg_add(typename PbAcc<T>::type *ys, int row, T v, int lane, bool fold_ok) {
+  typedef typename PbAcc<T>::type acc_t;
   const int rprev = wshfl_up(row, 1);
   const bool head = lane == 0 || rprev != row;
   const unsigned long long heads = __ballot(head);
-  if (heads != ~0ull) {  // some lane continues its neighbour's row: segmented inclusive scan over the wavefront
+  // fold when at least half of the lanes continue their neighbour's row (heavy rows: atomics on one address are
+  // serial, 3 cycles each); otherwise the few repeats are cheaper than the fold
+  if (fold_ok && __popcll(heads) <= 32) {
     const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
     const int head_pos = 63 - __builtin_clzll(below);  // lane 0 is always a head, so below != 0
 #pragma unroll
@@ -184,59 +214,112 @@ __device__ __forceinline__ void pb_seg_add(T *ys, int row, T v, int lane) {
       if (lane - d >= head_pos) v = (T)(v + up);
     }
     const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-    if (row >= 0 && tail) atomicAdd(&ys[row], v);
+    if (row >= 0 && tail) atomicAdd(&ys[row], (acc_t)v);
   } else if (row >= 0) {
-    atomicAdd(&ys[row], v);
+    atomicAdd(&ys[row], (acc_t)v);
   }
 }
+
+// A wavefront walks pieces (panel p, block wave, wave + 16, ...) in chunks of 64 U entries.  The piece bounds are
+// fetched 64 pieces at a time (lane = piece) and the entries of chunk i + 1 are requested before chunk i is
+// added, across piece ends, so that no dependent pointer -> entry round trip sits in the loop.
+template <class T, int U>
+struct PbChunk {
+  int64_t s, e;  // entries [s, e) of the current piece; this chunk covers s .. s + 64 U
+  int r[U];
+  T v[U];
+};
 
 template <class T, int U>
 __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__restrict__ piece_ptr,
                                                               const int64_t *__restrict__ panel_row,
                                                               const uint16_t *__restrict__ row16,
                                                               const T *__restrict__ prod, T *__restrict__ y,
-                                                              int64_t nb, int lab) {
-  __shared__ T ys[kPbSliceBytes / sizeof(T)];
-  const int tid = threadIdx.x, lane = tid & 63;
+                                                              int64_t np, int64_t nb, int lab) {
+  typedef typename PbAcc<T>::type acc_t;
+  __shared__ acc_t ys[kPbSliceBytes / sizeof(acc_t)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t p = blockIdx.x;
   const int64_t r0 = panel_row[p];
   const int rows = (int)(panel_row[p + 1] - r0);
-  const int64_t s = piece_ptr[p * nb], e = piece_ptr[(p + 1) * nb];
-  for (int j = tid; j < rows; j += kPbThreads) ys[j] = (T)0;
+  for (int j = tid; j < rows; j += kPbThreads) ys[j] = (acc_t)0;
   __syncthreads();
-  for (int64_t i0 = s; i0 < e; i0 += (int64_t)kPbThreads * U) {
-    int r[U];
-    T v[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int64_t ii = i0 + (int64_t)u * kPbThreads + tid;
-      const bool ok = ii < e;
-      r[u] = ok ? (int)ntload(&row16[ii]) : -1;
-      v[u] = ok ? ntload(&prod[ii]) : (T)0;
+  const int64_t npieces = wave < nb ? (nb - wave + kPbWaves - 1) / kPbWaves : 0;  // blocks wave, wave + 16, ...
+  int64_t ps = 0, pe = 0;  // bounds of piece (j & ~63) + lane of this wavefront's list
+  int64_t j = -1, cs = 0, ce = 0;
+  auto advance = [&]() -> bool {  // moves (cs, ce) to the next chunk; false when the pieces are used up
+    cs += 64 * U;
+    if (j >= 0 && cs < ce) return true;
+    for (j++; j < npieces; j++) {
+      if ((j & 63) == 0) {
+        const int64_t jj = j + lane;
+        ps = pe = 0;
+        if (jj < npieces) {
+          const int64_t k = (wave + jj * kPbWaves) * np + p;
+          ps = piece_ptr[k];
+          pe = piece_ptr[k + 1];
+        }
+      }
+      cs = pb_bcast64(ps, (int)(j & 63));
+      ce = pb_bcast64(pe, (int)(j & 63));
+      if (cs < ce) return true;
     }
+    return false;
+  };
+  auto load = [&](PbChunk<T, U> &ch) {
+    ch.s = cs;
+    ch.e = ce;
+#pragma unroll
+    for (int u = 0; u < U; u++) {  // never predicated (see pass 1): clamped address, the row masked afterwards
+      const int64_t ii = cs + lane + 64 * u;
+      const int64_t ic = ii < ce ? ii : ce - 1;
+      ch.r[u] = (int)ntload(&row16[ic]);
+      ch.v[u] = ntload(&prod[ic]);
+    }
+  };
+  auto add = [&](const PbChunk<T, U> &ch) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (lab == 0) pb_seg_add<T>(ys, r[u], v[u], lane);
-      else if (lab == 1) { if (r[u] == 12345 && v[u] == (T)77) ys[0] = v[u]; }  // lab: stream only
-      else if (r[u] >= 0) atomicAdd(&ys[r[u]], v[u]);                            // lab: plain atomics
+      if (ch.s + 64 * u >= ch.e) break;  // uniform: the piece ended in an earlier instruction of the chunk
+      if (lab == 1) { if (ch.r[u] == 12345 && ch.v[u] == (T)77) ys[0] = (acc_t)ch.v[u]; }  // lab: stream only
+      else pb_seg_add<T>(ys, ch.s + lane + 64 * u < ch.e ? ch.r[u] : -1, ch.v[u], lane, lab == 0);  // lab 2: plain atomics
+    }
+  };
+  if (advance()) {
+    PbChunk<T, U> A, B;
+    load(A);
+    for (;;) {
+      const bool more_b = advance();
+      if (more_b) load(B);
+      add(A);
+      if (!more_b) break;
+      const bool more_a = advance();
+      if (more_a) load(A);
+      add(B);
+      if (!more_a) break;
     }
   }
   __syncthreads();
-  for (int j = tid; j < rows; j += kPbThreads) y[r0 + j] = ys[j];
+  for (int j2 = tid; j2 < rows; j2 += kPbThreads) y[r0 + j2] = (T)ys[j2];
 }
 
 // Decides and, if worthwhile, builds the piece copy.  One-time host synchronisations.
+// vetted: called by reorder_prepare, which has already established that the record is large, that most tiles
+// span a wide column range and that column popularity is skewed (the default route, option 0).  Option 1 also
+// admits records of flat popularity (own checks below), 2 admits anything (tests), -1 nothing.
 template <class T>
-int pb_prepare(futhark_context *ctx, const CsrBody<T> *a) {
+int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted) {
   a->pb_state = -1;
-  if (ctx->opt_spmv_pb <= 0 || !a->col32 || a->nnz == 0 || a->n == 0 || a->tile <= 0) return 0;
-  const bool force = ctx->opt_spmv_pb > 1;  // tests: any record (2); 1: records that qualify by size and shape
+  if (ctx->opt_spmv_pb < 0 || (ctx->opt_spmv_pb == 0 && !vetted)) return 0;
+  if (!a->col32 || a->nnz == 0 || a->n == 0 || a->tile <= 0) return 0;
+  const bool force = ctx->opt_spmv_pb > 1;
   // slice sizes (overridable for tests so that small records have many panels and blocks)
   const int64_t slice = kPbSliceBytes / (int64_t)sizeof(T);
-  int64_t R = ctx->opt_spmv_pb_rows > 0 ? ctx->opt_spmv_pb_rows : slice;
+  const int64_t yslice = kPbSliceBytes / (int64_t)sizeof(typename PbAcc<T>::type);  // rows of y a panel can hold
+  int64_t R = ctx->opt_spmv_pb_rows > 0 ? ctx->opt_spmv_pb_rows : yslice;
   int64_t lpb = ctx->opt_spmv_pb_lines > 0 ? ctx->opt_spmv_pb_lines : slice / kPbLine;  // lines per block
   int64_t E = ctx->opt_spmv_pb_entries > 0 ? ctx->opt_spmv_pb_entries : kPbPanelEntries;
-  if (R > slice) R = slice;
+  if (R > yslice) R = yslice;
   if (R > 65536) R = 65536;  // 16-bit row offsets
   if (lpb * kPbLine > slice) lpb = slice / kPbLine;
   if (lpb * kPbLine > 65536) lpb = 65536 / kPbLine;
@@ -250,6 +333,8 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a) {
     if (sizeof(T) != 4 || a->m * (int64_t)sizeof(T) < kReorderMinBytes) return 0;
     const int64_t np_est = cdiv(a->n, R) + cdiv(a->nnz, E);
     if (a->nnz / (np_est * nb) < kPbMinPiece) return 0;
+  }
+  if (!force && !vetted) {
     unsigned long long *stat = reinterpret_cast<unsigned long long *>(ctx->d_small);
     SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
     hipLaunchKernelGGL(reorder_wide_tiles_kernel, dim3((unsigned)cdiv(a->ntiles, kBlock)), dim3(kBlock), 0, ctx->stream,
@@ -304,9 +389,12 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a) {
     SAMD_TRY(rank_of_line.get(nl));
     SAMD_HIP(ctx, hipMemsetAsync(counts.p, 0, sizeof(uint32_t) * (size_t)nl, ctx->stream));
     {
-      const int64_t want = cdiv(a->nnz, kBlock), cap = (int64_t)ctx->num_cu * 32;
+      int64_t stride = a->nnz >> 24;  // about 2^24 samples
+      if (stride < 1) stride = 1;
+      if (stride % 2 == 0) stride++;  // odd: no resonance with even row lengths
+      const int64_t want = cdiv(cdiv(a->nnz, stride), kBlock), cap = (int64_t)ctx->num_cu * 32;
       hipLaunchKernelGGL(pb_line_count_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(kBlock), 0, ctx->stream,
-                         (const int32_t *)a->col32, a->nnz, counts.p);
+                         (const int32_t *)a->col32, a->nnz, stride, counts.p);
       SAMD_LAUNCH_CHECK(ctx);
     }
     const unsigned lgrid = (unsigned)cdiv(nl, kBlock);
@@ -345,7 +433,7 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a) {
     SAMD_TRY(pval.get(a->nnz));
     hipLaunchKernelGGL((pb_build_kernel<T>), dim3(egrid), dim3(kBlock), 0, ctx->stream, (const int64_t *)a->row_ptr,
                        (const int32_t *)a->col32, (const T *)a->vals, a->nnz, (const int64_t *)a->tile_lb, a->tile,
-                       (const int64_t *)panel_row.p, (const uint32_t *)rank_of_line.p, nb, (const uint32_t *)eks, eperm,
+                       (const int64_t *)panel_row.p, (const uint32_t *)rank_of_line.p, nb, np, (const uint32_t *)eks, eperm,
                        col16.p, row16.p, pval.p);
     SAMD_LAUNCH_CHECK(ctx);
     int64_t flag[3];
@@ -367,6 +455,8 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a) {
   a->pb_prod = prod.release();
   a->pb_x = xperm.release();
   a->pb_state = 1;
+  if (ctx->logging) fprintf(stderr, "[sparse_amd] two-pass SpMV: %lld panels x %lld blocks of %lld columns, %.0f entries per piece\n",
+                            (long long)np, (long long)nb, (long long)w, (double)a->nnz / (double)pieces);
   return 0;
 }
 
@@ -375,18 +465,17 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
   hipLaunchKernelGGL((pb_xperm_kernel<T>), dim3((unsigned)cdiv(a->pb_nl * kPbLine, kBlock)), dim3(kBlock), 0, ctx->stream,
                      x, a->m, (const uint32_t *)a->pb_line_of_rank, a->pb_nl, a->pb_nb, a->pb_w, a->pb_x);
   SAMD_LAUNCH_CHECK(ctx);
-  // pass 1: at least ~4 workgroups per CU's worth of work units so that the tail is short
+  // pass 1: about 4 workgroups per CU so that the tail is short
   int64_t split = cdiv((int64_t)ctx->num_cu * 4, a->pb_nb);
   if (split < 1) split = 1;
-  if (split > cdiv(a->pb_np, kPbWaves)) split = cdiv(a->pb_np, kPbWaves);
   if (split > 65535) split = 65535;
-  hipLaunchKernelGGL((pb_pass1_kernel<T, 4>), dim3((unsigned)a->pb_nb, (unsigned)split), dim3(kPbThreads), 0, ctx->stream,
+  hipLaunchKernelGGL((pb_pass1_kernel<T, 8>), dim3((unsigned)a->pb_nb, (unsigned)split), dim3(kPbThreads), 0, ctx->stream,
                      (const int64_t *)a->pb_piece_ptr, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,
-                     (const T *)a->pb_x, a->pb_prod, a->pb_np, a->pb_nb, (int)a->pb_w, (int)((ctx->opt_ablate >> 2) & 3));
+                     (const T *)a->pb_x, a->pb_prod, a->pb_np, (int)a->pb_w, (int)((ctx->opt_ablate >> 2) & 3));
   SAMD_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL((pb_pass2_kernel<T, 8>), dim3((unsigned)a->pb_np), dim3(kPbThreads), 0, ctx->stream,
                      (const int64_t *)a->pb_piece_ptr, (const int64_t *)a->pb_panel_row, (const uint16_t *)a->pb_row16,
-                     (const T *)a->pb_prod, y, a->pb_nb, (int)(ctx->opt_ablate & 3));
+                     (const T *)a->pb_prod, y, a->pb_np, a->pb_nb, (int)(ctx->opt_ablate & 3));
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
 }

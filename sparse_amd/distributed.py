@@ -139,6 +139,11 @@ class ExchangePlan:
             self.own_offset = self.lo
             self.ghost = None
             self.equal_slices = len({self.bounds[k + 1] - self.bounds[k] for k in range(self.world)}) == 1
+            # gloo with CUDA tensors (the single-GPU rehearsal of the N>1 path) stages through the host and its
+            # all_gather_into_tensor was seen to hang there once: point-to-point transfers in that case
+            if dist is not None and self.world > 1 and dist.get_backend() == "gloo" and \
+                    torch.device(device).type == "cuda":
+                self.equal_slices = False
             self.send_idx = None
             self.send_counts = [0 if k == self.rank else self.n_own for k in range(self.world)]
             self.recv_counts = [0 if k == self.rank else self.bounds[k + 1] - self.bounds[k] for k in range(self.world)]

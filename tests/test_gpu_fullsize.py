@@ -177,3 +177,37 @@ def test_c3_hot_column_renumbering_against_the_plain_kernel():
         finally:
             ctx.set_option("spmv_reorder", 0)
     assert torch.equal(ys[0], ys[1])
+
+
+def test_c3_two_pass_product_is_chosen_and_within_tolerance():
+    """configs[2] at scale 22: a large, wide, skewed f32 record takes the two-pass product (x and y slices in
+    LDS) by itself; against the plain one-pass kernel on a fresh record within the f32 bar (1e-5 relative: the
+    two-pass sum is accumulated in f64 in another order), and for integer values exactly."""
+    torch, ctx = _ctx()
+    from sparse_amd import mk_compressed, synth
+    n = 1 << 22
+    r, c, v = synth.rmat_coo_device(22, 18, "cuda:0", "f32")
+    x = torch.rand(n, device="cuda:0", dtype=torch.float32) + 0.5
+    M = mk_compressed("f32", ctx)
+    A = M.sr.sparse(n, n, (r, c, v))
+    y = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0").clone()
+    assert ctx.get_option("spmv_last_path") == 3, "the two-pass path was not chosen"
+    y_again = torch.as_tensor(M.sr.smvm(A, 2 * x), device="cuda:0").clone()      # cached pieces, another x
+    ctx.set_option("spmv_pb", -1)
+    ctx.set_option("spmv_reorder", -1)
+    try:
+        A2 = M.sr.sparse(n, n, (r, c, v))
+        y2 = torch.as_tensor(M.sr.smvm(A2, x), device="cuda:0").clone()
+        assert ctx.get_option("spmv_last_path") == 0
+        assert float(((y - y2).abs() / y2.abs().clamp_min(1e-30)).max()) <= 1e-5
+        assert float(((y_again - 2 * y2).abs() / y2.abs().clamp_min(1e-30)).max()) <= 2e-5
+        Mi = mk_compressed("i32", ctx)
+        vi = (v * 8).to(torch.int32)
+        xi = (x * 8).to(torch.int32)
+        yi2 = torch.as_tensor(Mi.sr.smvm(Mi.sr.sparse(n, n, (r, c, vi)), xi), device="cuda:0").clone()
+    finally:
+        ctx.set_option("spmv_pb", 0)
+        ctx.set_option("spmv_reorder", 0)
+    yi = torch.as_tensor(Mi.sr.smvm(Mi.sr.sparse(n, n, (r, c, vi)), xi), device="cuda:0")
+    assert ctx.get_option("spmv_last_path") == 3
+    assert torch.equal(yi, yi2)

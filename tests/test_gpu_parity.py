@@ -307,7 +307,7 @@ def test_smvm_column_blocks(ctx, dtype, width):
 @pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
 @pytest.mark.parametrize("geom", [(0, 0, 0), (64, 2, 2048), (700, 5, 4096)], ids=["one_piece", "tiny", "mid"])
 def test_smvm_two_pass_panels(ctx, dtype, geom):
-    """spmv_pb=2 forces the two-pass product (opt-in, measured slower than the one-pass path: kept as a record): entries regrouped
+    """spmv_pb=2 forces the two-pass product (normally kept for large, wide, skewed records of 4-byte values): entries regrouped
     into (row panel) x (column block) pieces, products streamed out, then added per panel.  The overrides
     shrink panels and blocks so that small records have many of both.  Against the oracle within the dtype's
     bar (the summation order differs from the oracle's), i32 exact; a second x on the cached pieces; a very
