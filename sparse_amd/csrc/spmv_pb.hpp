@@ -30,6 +30,9 @@
 //   * walking pieces costs: with the layout [panel][block] (pass 1 walks ~300-entry pieces and writes them, pass 2
 //     streams) pass 1 took 1.1-1.4 ms; entries per panel E = 1 M / 512 K / 256 K / 128 K / 64 K give pass 2
 //     1.22 / 0.96 / 0.94 / 0.99 / 1.27 ms (heavy panels are slow per entry, small pieces are slow per piece).
+//   * pass 2 is not waiting for memory: a ring of four chunks (three in flight per wavefront instead of one) ran
+//     0.99 ms against 0.94; without the LDS accumulation the same walk takes 0.51 ms -- the ~56 cycles of LDS work
+//     per 64 entries (one ds_add_f64 = 27 of them) are what it pays.
 //   * shipped: 0.06 + 0.66 + 0.94 = 1.66 ms per product against 2.08 ms for the one-pass kernel with hot-column
 //     renumbering (19.8 % of HBM peak on the algorithmic bytes against 15.9 %).  One-off set-up 40 ms.
 // Default for large, wide, skewed records of 4-byte values (reorder_prepare hands them over); 8-byte values stay
