@@ -51,6 +51,7 @@ constexpr int kPbLine = 32;                         // columns per line (the uni
 constexpr int kPbSliceBytes = 128 << 10;            // slice of x (pass 1) or y (pass 2) in LDS
 constexpr int64_t kPbPanelEntries = 256 << 10;      // a panel is closed once it holds this many entries (measured on C3:
                                                     // 1 M 1.22 ms, 512 K 0.96, 256 K 0.94, 128 K 0.99, 64 K 1.27 in pass 2)
+constexpr int kPbFoldMax = 16;                      // pass 2 folds a wavefront's runs when it holds at most this many (C3: 2: 0.95 ms, 8: 0.91, 16: 0.89, 32: 0.93, 48: 1.01)
 constexpr int64_t kPbMinPiece = 128;               // auto mode: mean entries per piece below this -> not worth it
 
 // Popularity of the 32-column lines from every stride-th entry: the ranking only has to deal the lines to the
@@ -201,14 +202,14 @@ template <class T> struct PbAcc { typedef double type; };
 template <> struct PbAcc<int32_t> { typedef int32_t type; };
 
 template <class T>
-__device__ __forceinline__ void pb_seg_add(typename PbAcc<T>::type *ys, int row, T v, int lane, bool fold_ok) {
+__device__ __forceinline__ void pb_seg_add(typename PbAcc<T>::type *ys, int row, T v, int lane, int fold_max) {
   typedef typename PbAcc<T>::type acc_t;
   const int rprev = wshfl_up(row, 1);
   const bool head = lane == 0 || rprev != row;
   const unsigned long long heads = __ballot(head);
   // fold when at least half of the lanes continue their neighbour's row (heavy rows: atomics on one address are
   // serial, 3 cycles each); otherwise the few repeats are cheaper than the fold
-  if (fold_ok && __popcll(heads) <= 32) {
+  if (__popcll(heads) <= fold_max) {
     const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
     const int head_pos = 63 - __builtin_clzll(below);  // lane 0 is always a head, so below != 0
 #pragma unroll
@@ -228,7 +229,7 @@ __device__ __forceinline__ void pb_seg_add(typename PbAcc<T>::type *ys, int row,
 // added, across piece ends, so that no dependent pointer -> entry round trip sits in the loop.
 template <class T, int U>
 struct PbChunk {
-  int64_t s, e;  // entries [s, e) of the current piece; this chunk covers s .. s + 64 U
+  int n;  // entries of this chunk (1 .. 64 U), the same in every lane
   int r[U];
   T v[U];
 };
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__r
                                                               const int64_t *__restrict__ panel_row,
                                                               const uint16_t *__restrict__ row16,
                                                               const T *__restrict__ prod, T *__restrict__ y,
-                                                              int64_t np, int64_t nb, int lab) {
+                                                              int64_t np, int64_t nb, int lab, int fold_max) {
   typedef typename PbAcc<T>::type acc_t;
   __shared__ acc_t ys[kPbSliceBytes / sizeof(acc_t)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -269,23 +270,27 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__r
     }
     return false;
   };
+  // Everything per lane is 32-bit and relative to the chunk (the chunk's base pointers are wavefront-uniform):
+  // with 64-bit indices per lane this kernel issued 63 vector instructions per 64 entries and was bound by them.
   auto load = [&](PbChunk<T, U> &ch) {
-    ch.s = cs;
-    ch.e = ce;
+    const uint16_t *rp = row16 + cs;
+    const T *vp = prod + cs;
+    const int n = (int)(ce - cs < (int64_t)(64 * U) ? ce - cs : (int64_t)(64 * U));
+    ch.n = n;
 #pragma unroll
-    for (int u = 0; u < U; u++) {  // never predicated (see pass 1): clamped address, the row masked afterwards
-      const int64_t ii = cs + lane + 64 * u;
-      const int64_t ic = ii < ce ? ii : ce - 1;
-      ch.r[u] = (int)ntload(&row16[ic]);
-      ch.v[u] = ntload(&prod[ic]);
+    for (int u = 0; u < U; u++) {  // never predicated (see pass 1): clamped offset, the row masked afterwards
+      const int o = lane + 64 * u;
+      const int oc = o < n ? o : n - 1;
+      ch.r[u] = (int)ntload(rp + oc);
+      ch.v[u] = ntload(vp + oc);
     }
   };
   auto add = [&](const PbChunk<T, U> &ch) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (ch.s + 64 * u >= ch.e) break;  // uniform: the piece ended in an earlier instruction of the chunk
+      if (64 * u >= ch.n) break;  // uniform: the piece ended in an earlier instruction of the chunk
       if (lab == 1) { if (ch.r[u] == 12345 && ch.v[u] == (T)77) ys[0] = (acc_t)ch.v[u]; }  // lab: stream only
-      else pb_seg_add<T>(ys, ch.s + lane + 64 * u < ch.e ? ch.r[u] : -1, ch.v[u], lane, lab == 0);  // lab 2: plain atomics
+      else pb_seg_add<T>(ys, lane + 64 * u < ch.n ? ch.r[u] : -1, ch.v[u], lane, fold_max);  // lab 2: plain atomics
     }
   };
   if (advance()) {
@@ -478,7 +483,8 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
   SAMD_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL((pb_pass2_kernel<T, 8>), dim3((unsigned)a->pb_np), dim3(kPbThreads), 0, ctx->stream,
                      (const int64_t *)a->pb_piece_ptr, (const int64_t *)a->pb_panel_row, (const uint16_t *)a->pb_row16,
-                     (const T *)a->pb_prod, y, a->pb_np, a->pb_nb, (int)(ctx->opt_ablate & 3));
+                     (const T *)a->pb_prod, y, a->pb_np, a->pb_nb, (int)(ctx->opt_ablate & 3),
+                     (ctx->opt_ablate & 3) == 2 ? 0 : (ctx->opt_ablate >> 4) ? (int)(ctx->opt_ablate >> 4) : kPbFoldMax);
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
 }
