@@ -52,6 +52,8 @@ constexpr int kPbSliceBytes = 128 << 10;            // slice of x (pass 1) or y 
 constexpr int64_t kPbPanelEntries = 256 << 10;      // a panel is closed once it holds this many entries (measured on C3:
                                                     // 1 M 1.22 ms, 512 K 0.96, 256 K 0.94, 128 K 0.99, 64 K 1.27 in pass 2)
 constexpr int kPbFoldMax = 16;                      // pass 2 folds a wavefront's runs when it holds at most this many (C3: 2: 0.95 ms, 8: 0.91, 16: 0.89, 32: 0.93, 48: 1.01)
+constexpr int64_t kPbMinBytes = 16 << 20;            // x at least this large (RMAT f32, bench/pb_scale_sweep.py, two-pass / one-pass ms:
+                                                    // scale 20 0.21 / 0.15, 21 0.264 / 0.259, 22 0.47 / 0.51, 23 0.81 / 1.01, 24 1.62 / 2.08)
 constexpr int64_t kPbMinPiece = 128;               // auto mode: mean entries per piece below this -> not worth it
 
 // Popularity of the 32-column lines from every stride-th entry: the ranking only has to deal the lines to the
@@ -338,7 +340,7 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted) {
   if (!force) {
     // the gather has to be the problem: 4-byte values (16 B moved per entry against 8; for 8-byte values the
     // one-pass paths are on par), x beyond the L2s, most tiles spanning a wide column range
-    if (sizeof(T) != 4 || a->m * (int64_t)sizeof(T) < kReorderMinBytes) return 0;
+    if (sizeof(T) != 4 || a->m * (int64_t)sizeof(T) < kPbMinBytes) return 0;
     const int64_t np_est = cdiv(a->n, R) + cdiv(a->nnz, E);
     if (a->nnz / (np_est * nb) < kPbMinPiece) return 0;
   }
