@@ -33,8 +33,10 @@
 //   * pass 2 is not waiting for memory: a ring of four chunks (three in flight per wavefront instead of one) ran
 //     0.99 ms against 0.94; without the LDS accumulation the same walk takes 0.51 ms -- the ~56 cycles of LDS work
 //     per 64 entries (one ds_add_f64 = 27 of them) are what it pays.
-//   * shipped: 0.06 + 0.66 + 0.94 = 1.66 ms per product against 2.08 ms for the one-pass kernel with hot-column
-//     renumbering (19.8 % of HBM peak on the algorithmic bytes against 15.9 %).  One-off set-up 40 ms.
+//   * pass 2 was issuing 63 vector instructions per 64 entries, most of them the in-wavefront fold: folding only
+//     when a wavefront holds <= 16 runs (instead of <= 32) 0.93 -> 0.89 ms.
+//   * shipped: 0.06 + 0.66 + 0.89 = 1.60 ms per product against 2.08 ms for the one-pass kernel with hot-column
+//     renumbering (20.5 % of HBM peak on the algorithmic bytes against 15.9 %).  One-off set-up 40 ms.
 // Default for large, wide, skewed records of 4-byte values (reorder_prepare hands them over); 8-byte values stay
 // on the one-pass paths (28 B per entry here against 12).
 #pragma once
