@@ -148,10 +148,14 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
 
   if (tid == 0) nlong = 0;
   const int grp = tid / L, sub = tid & (L - 1), ngrp = kBlock / L;
+  // Rows are dealt to the lane groups so that group g holds a row with (row & 15) == (g & 15): the y stores of a
+  // wavefront then cover whole 128-byte lines instead of straddling them (ngrp is a multiple of 16 for L <= 16).
+  const int shift = ngrp >= 16 ? (int)(rfirst & 15) : 0;
+  const int j0 = grp - shift;
   int64_t rs0 = 0, re0 = 0;  // first row's bounds, requested before the barrier
-  if (grp < nrows) {
-    rs0 = ntload(&row_ptr[rfirst + grp]);
-    re0 = ntload(&row_ptr[rfirst + grp + 1]);
+  if (j0 >= 0 && j0 < nrows) {
+    rs0 = ntload(&row_ptr[rfirst + j0]);
+    re0 = ntload(&row_ptr[rfirst + j0 + 1]);
   }
   __syncthreads();
 
@@ -180,10 +184,11 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
   }
 
   // ---- phase 2: L lanes per row fragment, row-major gather of x
-  for (int j = grp; j < nrows; j += ngrp) {
+  for (int j = j0; j < nrows; j += ngrp) {
+    if (j < 0) continue;
     const int64_t r = rfirst + j;
     int64_t rs, re;
-    if (j == grp) { rs = rs0; re = re0; }
+    if (j == j0) { rs = rs0; re = re0; }
     else { rs = ntload(&row_ptr[r]); re = ntload(&row_ptr[r + 1]); }
     if (r < lb0) {
       if (re <= base) continue;                                              // candidate head row does not reach this tile
