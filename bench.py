@@ -88,6 +88,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+    if dist is not None and args.backend == "gloo":
+        from sparse_amd.distributed import HostStagedDist
+        dist = HostStagedDist(dist)      # rehearsal with ranks sharing a GPU: collectives go through CPU copies
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -202,9 +205,10 @@ def main():
     if rank == 0:
         ms = el / args.steps * 1e3
         gflops = 2.0 * nnz_glob / (el / args.steps) / 1e9
-        # algorithmic bytes of one launch on this rank: entries (8 B value + 4 B i32 column index as
-        # resident on the device) + row_ptr 8 B and y 8 B per row + x 8 B per referenced column
-        alg_bytes = nnz * 12 + n_loc * 8 + n_loc * 8 + m_loc * 8
+        # algorithmic bytes of one launch on this rank, as resident on the device and read by the kernel:
+        # entries (8 B value + 4 B i32 column index) + row offsets 2 B (tile-relative u16, row_rel) and y 8 B per
+        # row + x 8 B per referenced column
+        alg_bytes = nnz * 12 + n_loc * 2 + n_loc * 8 + m_loc * 8
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -219,7 +223,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D 5-point Laplacian CSR f64, %d^2 grid per GPU, SpMV (BASELINE configs[1])" % g,
-                       "rows_per_gpu": n_loc, "nnz_per_gpu": nnz, "nnz_total": nnz_glob, "col_idx_bytes": 4,
+                       "rows_per_gpu": n_loc, "nnz_per_gpu": nnz, "nnz_total": nnz_glob, "col_idx_bytes": 4, "row_offset_bytes": 2,
                        "x_exchange": "none" if D is None else D.mode, "x_exchange_ms_alone": round(ex_ms, 5),
                        "assembly_s": round(asm_s, 4), "assembly_Mtriples_per_s": round(nnz0 / asm_s / 1e6, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -231,7 +235,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        import torch.distributed as tdist
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":

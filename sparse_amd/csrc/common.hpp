@@ -234,6 +234,7 @@ struct CsrBody {
   int64_t *tile_lb = nullptr;
   T *head = nullptr;
   int64_t max_row_len = -1;  // filled lazily by the SpMV dispatcher
+  mutable uint16_t *row_rel = nullptr;  // [n + 1] row starts relative to their tile (spmv.hpp: row_rel_kernel); built lazily
   // plan statistics (tile_lb[ntiles+1], [ntiles+2]), read back once by the first product
   mutable int64_t spill_max = -1;      // longest first spill
   mutable int64_t max_tile_rows = -1;  // most rows starting in one tile
@@ -275,6 +276,7 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->vals);
   dfree(ctx, b->tile_lb);
   dfree(ctx, b->head);
+  dfree(ctx, b->row_rel);
   dfree(ctx, b->col_hot);
   dfree(ctx, b->hot_perm);
   dfree(ctx, b->x_hot);

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
                                                              const T *__restrict__ x, T *__restrict__ y,
                                                              const int64_t *__restrict__ tile_lb,
                                                              T *__restrict__ head, int64_t nnz, int64_t ntiles,
-                                                             int force_lanes) {
+                                                             int force_lanes, const uint16_t *__restrict__ row_rel) {
   __shared__ __attribute__((aligned(16))) T sval[TILE + (INLINE ? kSpillInline : 0)];
   __shared__ __attribute__((aligned(16))) I scol[TILE + (INLINE ? kSpillInline : 0)];
   __shared__ int longrows[TILE / 16 + 6];
@@ -153,9 +153,17 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
   const int shift = ngrp >= 16 ? (int)(rfirst & 15) : 0;
   const int j0 = grp - shift;
   int64_t rs0 = 0, re0 = 0;  // first row's bounds, requested before the barrier
-  if (j0 >= 0 && j0 < nrows) {
-    rs0 = ntload(&row_ptr[rfirst + j0]);
-    re0 = ntload(&row_ptr[rfirst + j0 + 1]);
+  int a0 = 0, b0 = 0;        // ... or its 16-bit tile-relative form (large records, see row_rel_kernel)
+  if (INLINE) {
+    if (j0 >= 0 && j0 < nrows) {
+      rs0 = ntload(&row_ptr[rfirst + j0]);
+      re0 = ntload(&row_ptr[rfirst + j0 + 1]);
+    }
+  } else {
+    // never behind a branch (a 16-bit load behind a branch is waited for at once): clamped index, masked later
+    const int jc = j0 < 0 ? 0 : (j0 < nrows ? j0 : (nrows > 0 ? nrows - 1 : 0));
+    a0 = (int)ntload(&row_rel[rfirst + jc]);
+    b0 = (int)ntload(&row_rel[rfirst + jc + 1]);
   }
   __syncthreads();
 
@@ -187,15 +195,30 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
   for (int j = j0; j < nrows; j += ngrp) {
     if (j < 0) continue;
     const int64_t r = rfirst + j;
-    int64_t rs, re;
-    if (j == j0) { rs = rs0; re = re0; }
-    else { rs = ntload(&row_ptr[r]); re = ntload(&row_ptr[r + 1]); }
-    if (r < lb0) {
-      if (re <= base) continue;                                              // candidate head row does not reach this tile
-      if (INLINE && re - (rs / TILE + 1) * TILE <= kSpillInline) continue;   // ... or was finished by its owner
+    int s, e;
+    bool to_y;
+    if (INLINE) {
+      int64_t rs, re;
+      if (j == j0) { rs = rs0; re = re0; }
+      else { rs = ntload(&row_ptr[r]); re = ntload(&row_ptr[r + 1]); }
+      if (r < lb0) {
+        if (re <= base) continue;                                    // candidate head row does not reach this tile
+        if (re - (rs / TILE + 1) * TILE <= kSpillInline) continue;   // ... or was finished by its owner
+      }
+      s = (int)((rs > base ? rs : base) - base);
+      e = (int)((re < lim2 ? re : lim2) - base);
+      to_y = rs >= base;
+    } else {
+      // Tile-relative bounds from row_rel (2 bytes per row instead of 8): a row that starts here begins at its own
+      // offset; any row ends where the next row starting here begins, or runs to the end of the tile.
+      int a, b;
+      if (j == j0) { a = a0; b = b0; }
+      else { a = (int)ntload(&row_rel[r]); b = (int)ntload(&row_rel[r + 1]); }
+      to_y = r >= lb0;
+      s = to_y ? a : 0;
+      e = r + 1 < lb1 ? b : cnt;
+      if (!to_y && e <= 0) continue;  // candidate head row does not reach this tile
     }
-    const int s = (int)((rs > base ? rs : base) - base);
-    const int e = (int)((re < lim2 ? re : lim2) - base);
     if (e - s > 16 * L) {
       if (sub == 0) {
         const int slot = atomicAdd(&nlong, 1);
@@ -208,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
     T acc = row_partial<T, I, U>(sval, scol, x, s, e, sub, L);
     for (int d = L >> 1; d >= 1; d >>= 1) acc = (T)(acc + wshfl_xor(acc, d));
     if (sub == 0) {
-      if (rs >= base) __builtin_nontemporal_store(acc, &y[r]);
+      if (to_y) __builtin_nontemporal_store(acc, &y[r]);
       else head[t] = acc;
     }
   }
@@ -242,6 +265,19 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
       else head[t] = acc;
     }
   }
+}
+
+// row_rel[r] = start of row r relative to the tile it is listed in (0 .. TILE; TILE only for empty rows at the very
+// end of a record whose entry count is a multiple of TILE).  Built at a large record's first product: the stream
+// kernel then reads 2 bytes per row instead of 8 (declared in the algorithmic bytes: rb = 2).
+__global__ __launch_bounds__(kBlock) void row_rel_kernel(const int64_t *__restrict__ row_ptr, int64_t n, int64_t tile,
+                                                         int64_t ntiles, uint16_t *__restrict__ row_rel) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r > n) return;
+  const int64_t rs = row_ptr[r];
+  int64_t t = rs / tile;
+  if (t > ntiles - 1) t = ntiles - 1;
+  row_rel[r] = (uint16_t)(rs - t * tile);
 }
 
 // Adds the spilled fragments: for tile t whose head row started in tile t-1
@@ -654,10 +690,18 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
       const int64_t per_lane = (avg + L - 1) / L;
       unroll = per_lane <= 6 ? 6 : 8;
     }
+    if (!inl && !a->row_rel) {
+      uint16_t *rel = nullptr;
+      SAMD_TRY(dalloc(ctx, &rel, a->n + 1));
+      hipLaunchKernelGGL(row_rel_kernel, dim3((unsigned)cdiv(a->n + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
+                         (const int64_t *)a->row_ptr, a->n, a->tile, a->ntiles, rel);
+      SAMD_LAUNCH_CHECK(ctx);
+      a->row_rel = rel;
+    }
 #define SAMD_SPMV_LAUNCH(INL, UU)                                                                                  \
   hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, INL, UU>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,   \
                      ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y,                      \
-                     (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force)
+                     (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force, (const uint16_t *)a->row_rel)
     if (inl) { if (unroll == 6) SAMD_SPMV_LAUNCH(true, 6); else SAMD_SPMV_LAUNCH(true, 8); }
     else { if (unroll == 6) SAMD_SPMV_LAUNCH(false, 6); else SAMD_SPMV_LAUNCH(false, 8); }
 #undef SAMD_SPMV_LAUNCH

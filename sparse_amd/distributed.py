@@ -24,6 +24,74 @@ the sorted ghost list), so the per-step path has no index translation.
 import numpy as np
 
 
+class HostStagedDist:
+    """torch.distributed look-alike for REHEARSING the N>1 path with several ranks on one GPU (backend gloo,
+    CUDA tensors): every collective and transfer goes through CPU copies.  gloo's own handling of CUDA tensors
+    hung intermittently on the GPU box (all_gather, all_gather_into_tensor) with two ranks sharing a device; on
+    CPU tensors it is reliable.  Not used with nccl/RCCL, where the tensors stay on the devices."""
+
+    isend, irecv = "isend", "irecv"
+
+    class _Work:
+        def __init__(self, works, recvs):
+            self.works, self.recvs = works, recvs
+
+        def wait(self):
+            for w in self.works:
+                w.wait()
+            for dst, host in self.recvs:
+                dst.copy_(host)
+            self.works, self.recvs = [], []
+
+    def __init__(self, dist):
+        self.d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    @staticmethod
+    def P2POp(op, tensor, peer):
+        return (op, tensor, peer)
+
+    def get_rank(self):
+        return self.d.get_rank()
+
+    def get_world_size(self):
+        return self.d.get_world_size()
+
+    def get_backend(self):
+        return self.d.get_backend()
+
+    def barrier(self):
+        self.d.barrier()
+
+    def all_reduce(self, t, op=None):
+        c = t.cpu()
+        self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
+        t.copy_(c)
+
+    def all_gather(self, outs, t):
+        co = [o.cpu() for o in outs]
+        self.d.all_gather(co, t.cpu())
+        for o, c in zip(outs, co):
+            o.copy_(c)
+
+    def all_gather_into_tensor(self, out, t):
+        c = out.cpu()
+        self.d.all_gather_into_tensor(c, t.cpu().contiguous())
+        out.copy_(c)
+
+    def batch_isend_irecv(self, ops):
+        import torch
+        real, recvs = [], []
+        for kind, t, peer in ops:
+            if kind == "isend":
+                real.append(self.d.P2POp(self.d.isend, t.cpu().contiguous(), peer))
+            else:
+                host = torch.empty(t.shape, dtype=t.dtype)
+                recvs.append((t, host))
+                real.append(self.d.P2POp(self.d.irecv, host, peer))
+        return [self._Work(self.d.batch_isend_irecv(real), recvs)]
+
+
 def partition_rows_equal_nnz(row_off, parts):
     """Row-block boundaries with (nearly) equal stored entries per part.
     row_off: the reference-convention inclusive prefix sum (length n), host array.
@@ -139,11 +207,6 @@ class ExchangePlan:
             self.own_offset = self.lo
             self.ghost = None
             self.equal_slices = len({self.bounds[k + 1] - self.bounds[k] for k in range(self.world)}) == 1
-            # gloo with CUDA tensors (the single-GPU rehearsal of the N>1 path) stages through the host and its
-            # all_gather_into_tensor was seen to hang there once: point-to-point transfers in that case
-            if dist is not None and self.world > 1 and dist.get_backend() == "gloo" and \
-                    torch.device(device).type == "cuda":
-                self.equal_slices = False
             self.send_idx = None
             self.send_counts = [0 if k == self.rank else self.n_own for k in range(self.world)]
             self.recv_counts = [0 if k == self.rank else self.bounds[k + 1] - self.bounds[k] for k in range(self.world)]

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from sparse_amd import Context, mk_compressed, synth  # noqa: E402
-from sparse_amd.distributed import DistCsr  # noqa: E402
+from sparse_amd.distributed import DistCsr, HostStagedDist  # noqa: E402
 
 
 def t(a, dev):
@@ -24,6 +24,7 @@ def main():
     faulthandler.dump_traceback_later(100, exit=True)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    hd = HostStagedDist(dist)      # ranks share one GPU: collectives through CPU copies (gloo + CUDA tensors hung)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     ctx = Context(0)
@@ -48,7 +49,7 @@ def main():
     C_ref = np.asarray(M.sr.smm(G, B))
 
     # distributed assembly, global column numbering, one record per rank: bit-equal row blocks
-    D = DistCsr.from_coo_chunks(M, dist, n, n, t(chunk(r), dev), t(chunk(c), dev), t(chunk(v), dev),
+    D = DistCsr.from_coo_chunks(M, hd, n, n, t(chunk(r), dev), t(chunk(c), dev), t(chunk(v), dev),
                                 force_mode="allgather", split=False)
     lo, hi = D.bounds[rank], D.bounds[rank + 1]
     off = D.nnz_offset()
@@ -57,7 +58,7 @@ def main():
     assert np.array_equal(l_ci, g_ci[off:off + len(l_ci)]), "col_idx"
     assert l_va.tobytes() == g_va[off:off + len(l_va)].tobytes(), "vals"
     for mode in ("allgather", "halo", None):
-        D = DistCsr.from_coo_chunks(M, dist, n, n, t(chunk(r), dev), t(chunk(c), dev), t(chunk(v), dev),
+        D = DistCsr.from_coo_chunks(M, hd, n, n, t(chunk(r), dev), t(chunk(c), dev), t(chunk(v), dev),
                                     force_mode=mode)
         lo, hi = D.bounds[rank], D.bounds[rank + 1]
         y = D.smvm(t(x[lo:hi], dev)).cpu().numpy()
@@ -73,7 +74,7 @@ def main():
     x2 = 1.0 + (np.arange(n2) % 5).astype(np.float64)
     y2 = np.asarray(M.sr.smvm(G2, x2))
     perm = synth.splitmix64(31, np.arange(len(rb), dtype=np.uint64)).argsort()
-    D2 = DistCsr.from_coo_chunks(M, dist, n2, n2, t(chunk(rb[perm]), dev), t(chunk(cb[perm]), dev),
+    D2 = DistCsr.from_coo_chunks(M, hd, n2, n2, t(chunk(rb[perm]), dev), t(chunk(cb[perm]), dev),
                                  t(chunk(vb[perm]), dev))
     assert D2.mode == "halo" and D2.A_gh is not None
     lo, hi = D2.bounds[rank], D2.bounds[rank + 1]
