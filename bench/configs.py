@@ -104,7 +104,8 @@ def main():
         ms = timed(lambda: M.sr.smvm(A, x), args.steps, torch)
         # row offsets as the kernel reads them: 2 B (tile-relative u16) on the one-pass stream path of large records
         rb = 2 if (ctx.get_option("spmv_last_path") == 0 and nnz > 4096 * 1024 and not args.algo) else 8
-        byt = nnz * (vb + 4) + n * rb + n * vb + m * vb
+        ib = ctx.get_option("spmv_last_col_bytes") if ctx.get_option("spmv_last_path") == 0 else 4
+        byt = nnz * (vb + ib) + n * rb + n * vb + m * vb
         out.update({"spmv_ms": round(ms, 4), "spmv_GFLOPs": round(2 * nnz / ms / 1e6, 1),
                     "spmv_GBs": round(byt / ms / 1e6, 1), "spmv_frac_peak": round(byt / ms / 1e6 / PEAK, 4)})
         if args.compare:

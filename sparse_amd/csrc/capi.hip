@@ -557,6 +557,7 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_cblk")) ctx->opt_spmv_cblk = value;
   else if (!strcmp(key, "sort_algo")) ctx->opt_sort_algo = value;
   else if (!strcmp(key, "spmv_reorder")) ctx->opt_spmv_reorder = value;
+  else if (!strcmp(key, "spmv_col16")) ctx->opt_spmv_col16 = value;
   else if (!strcmp(key, "spmv_pb")) ctx->opt_spmv_pb = value;
   else if (!strcmp(key, "spmv_pb_rows")) ctx->opt_spmv_pb_rows = value;
   else if (!strcmp(key, "spmv_pb_lines")) ctx->opt_spmv_pb_lines = value;
@@ -577,6 +578,8 @@ int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *k
   if (!strcmp(key, "spmv_pb")) return ctx->opt_spmv_pb;
   if (!strcmp(key, "num_cu")) return ctx->num_cu;
   if (!strcmp(key, "spmv_last_path")) return ctx->last_spmv_path;
+  if (!strcmp(key, "spmv_last_col_bytes")) return ctx->last_spmv_col_bytes;
+  if (!strcmp(key, "spmv_col16")) return ctx->opt_spmv_col16;
   return -1;
 }
 const char *sparse_amd_version(void) { return "sparse_amd 0.1 (gfx950)"; }

@@ -122,6 +122,8 @@ struct futhark_context {
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
   // statistics for futhark_context_report
   int64_t n_entries = 0;
+  int64_t last_spmv_col_bytes = 0;  // bytes per column index the last SpMV kernel read (2, 4 or 8)
+  int64_t opt_spmv_col16 = 0;  // 16-bit tile-relative columns: 0 decided per record, -1 never
   int64_t last_spmv_path = 0;  // 0 one-pass, 1 hot-column renumbering, 2 column blocks, 3 two passes (tests read it back)
 };
 
@@ -234,6 +236,11 @@ struct CsrBody {
   int64_t *tile_lb = nullptr;
   T *head = nullptr;
   int64_t max_row_len = -1;  // filled lazily by the SpMV dispatcher
+  // 16-bit columns relative to each tile's smallest column (spmv.hpp: col16_prepare), for records whose tiles all
+  // span fewer than 65536 columns (banded, stencil); built lazily at the first product of a large record
+  mutable int col16_state = 0;  // 0 undecided, 1 active, -1 rejected
+  mutable uint16_t *col16 = nullptr;   // [nnz]
+  mutable int32_t *tile_c0 = nullptr;  // [ntiles]
   mutable uint16_t *row_rel = nullptr;  // [n + 1] row starts relative to their tile (spmv.hpp: row_rel_kernel); built lazily
   // plan statistics (tile_lb[ntiles+1], [ntiles+2]), read back once by the first product
   mutable int64_t spill_max = -1;      // longest first spill
@@ -277,6 +284,8 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->tile_lb);
   dfree(ctx, b->head);
   dfree(ctx, b->row_rel);
+  dfree(ctx, b->col16);
+  dfree(ctx, b->tile_c0);
   dfree(ctx, b->col_hot);
   dfree(ctx, b->hot_perm);
   dfree(ctx, b->x_hot);

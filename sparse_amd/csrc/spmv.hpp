@@ -86,7 +86,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
                                                              const T *__restrict__ x, T *__restrict__ y,
                                                              const int64_t *__restrict__ tile_lb,
                                                              T *__restrict__ head, int64_t nnz, int64_t ntiles,
-                                                             int force_lanes, const uint16_t *__restrict__ row_rel) {
+                                                             int force_lanes, const uint16_t *__restrict__ row_rel,
+                                                             const int32_t *__restrict__ tile_c0) {
   __shared__ __attribute__((aligned(16))) T sval[TILE + (INLINE ? kSpillInline : 0)];
   __shared__ __attribute__((aligned(16))) I scol[TILE + (INLINE ? kSpillInline : 0)];
   __shared__ int longrows[TILE / 16 + 6];
@@ -97,21 +98,26 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
   const int64_t base = t * TILE;
   const int cnt = (int)((nnz - base) < (int64_t)TILE ? (nnz - base) : (int64_t)TILE);
   const int64_t lb0 = tile_lb[t], lb1 = tile_lb[t + 1];
+  // 16-bit columns are relative to the tile's smallest column (tile_c0): the tile gathers from x + that
+  const T *__restrict__ xt = sizeof(I) == 2 ? x + tile_c0[t] : x;
 
   // ---- phase 1: stream the tile into LDS (line-dense, non-temporal)
-  constexpr int CV = TILE * (int)sizeof(I) / (16 * kBlock);
+  constexpr int CW = TILE * (int)sizeof(I) / 16;  // 128-bit pieces of the tile's columns
+  constexpr int CV = CW / kBlock, CR = CW % kBlock;  // whole rounds of the block + a partial one (16-bit columns)
   constexpr int VV = TILE * (int)sizeof(T) / (16 * kBlock);
-  static_assert(CV >= 1 && VV >= 1, "tile too small for 128-bit loads");
+  static_assert(CW >= 1 && VV >= 1, "tile too small for 128-bit loads");
   if (cnt == TILE) {
-    raw16 c[CV], a[VV];
+    raw16 c[CV + 1], a[VV];
     const raw16 *cp = reinterpret_cast<const raw16 *>(col + base);
     const raw16 *vp = reinterpret_cast<const raw16 *>(val + base);
 #pragma unroll
     for (int it = 0; it < CV; it++) c[it] = ntload(cp + it * kBlock + tid);
+    if (CR) c[CV] = ntload(cp + CV * kBlock + (tid < CR ? tid : 0));  // unpredicated: clamped piece, stored by tid < CR only
 #pragma unroll
     for (int it = 0; it < VV; it++) a[it] = ntload(vp + it * kBlock + tid);
 #pragma unroll
     for (int it = 0; it < CV; it++) reinterpret_cast<raw16 *>(scol)[it * kBlock + tid] = c[it];
+    if (CR && tid < CR) reinterpret_cast<raw16 *>(scol)[CV * kBlock + tid] = c[CV];
 #pragma unroll
     for (int it = 0; it < VV; it++) reinterpret_cast<raw16 *>(sval)[it * kBlock + tid] = a[it];
   } else {
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
       const int64_t re = row_ptr[r + 1];
       if (INLINE && r < lb0 && re - (rs / TILE + 1) * TILE <= kSpillInline) continue;
       const int e = (int)((re < lim2 ? re : lim2) - base);
-      const T acc = row_partial<T, I, 4>(sval, scol, x, p, e, 0, 1);
+      const T acc = row_partial<T, I, 4>(sval, scol, xt, p, e, 0, 1);
       if (rs >= base) y[r] = acc;
       else head[t] = acc;
     }
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
     }
     // entries in flight per lane: as many as a typical fragment needs, no more (predicated-off slots
     // still cost issue slots); U is chosen per record on the host from its mean row length
-    T acc = row_partial<T, I, U>(sval, scol, x, s, e, sub, L);
+    T acc = row_partial<T, I, U>(sval, scol, xt, s, e, sub, L);
     for (int d = L >> 1; d >= 1; d >>= 1) acc = (T)(acc + wshfl_xor(acc, d));
     if (sub == 0) {
       if (to_y) __builtin_nontemporal_store(acc, &y[r]);
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(const int64_t *__re
         const bool ok = qq < e;
         const I cc = scol[ok ? qq : s];
         av[u] = ok ? sval[qq] : (T)0;
-        xv[u] = ok ? x[cc] : (T)0;
+        xv[u] = ok ? xt[cc] : (T)0;
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) acc = (T)(acc + (T)(av[u] * xv[u]));
@@ -655,6 +661,70 @@ int cblk_prepare(futhark_context *ctx, const CsrBody<T> *a) {
   return 0;
 }
 
+// ------------------------------------------------------------ 16-bit columns
+// One block per tile: the tile's smallest column goes to tile_c0, every column is stored as its 16-bit distance
+// from it; a tile spanning 65536 columns or more raises the flag (the record then keeps its 32-bit columns).
+__global__ __launch_bounds__(kBlock) void col16_build_kernel(const int32_t *__restrict__ col, int64_t nnz, int64_t tile,
+                                                             int32_t *__restrict__ tile_c0,
+                                                             uint16_t *__restrict__ col16, int *__restrict__ too_wide) {
+  __shared__ int smin[kWaves], smax[kWaves];
+  const int64_t base = (int64_t)blockIdx.x * tile;
+  const int per = (int)(tile / kBlock);
+  int mn = 0x7fffffff, mx = -1;
+  for (int k = 0; k < per; k++) {
+    const int64_t e = base + (int64_t)k * kBlock + threadIdx.x;
+    if (e < nnz) {
+      const int c = col[e];
+      mn = c < mn ? c : mn;
+      mx = c > mx ? c : mx;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int a = wshfl_xor(mn, d), b = wshfl_xor(mx, d);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    mn = smin[w] < mn ? smin[w] : mn;
+    mx = smax[w] > mx ? smax[w] : mx;
+  }
+  if (threadIdx.x == 0) {
+    tile_c0[blockIdx.x] = mn;
+    if ((int64_t)mx - (int64_t)mn > 65535) *too_wide = 1;
+  }
+  for (int k = 0; k < per; k++) {
+    const int64_t e = base + (int64_t)k * kBlock + threadIdx.x;
+    if (e < nnz) col16[e] = (uint16_t)(col[e] - mn);
+  }
+}
+
+// Decides and, if every tile qualifies, builds the 16-bit columns.  One-time host synchronisation.
+template <class T>
+int col16_prepare(futhark_context *ctx, const CsrBody<T> *a) {
+  a->col16_state = -1;
+  if (ctx->opt_spmv_col16 < 0 || !a->col32 || a->ntiles <= kInlineMaxTiles || a->tile != kSpmvTile) return 0;
+  Tmp<uint16_t> c16(ctx);
+  Tmp<int32_t> c0(ctx);
+  SAMD_TRY(c16.get(a->nnz));
+  SAMD_TRY(c0.get(a->ntiles));
+  int *flag = reinterpret_cast<int *>(ctx->d_small);
+  SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+  hipLaunchKernelGGL(col16_build_kernel, dim3((unsigned)a->ntiles), dim3(kBlock), 0, ctx->stream,
+                     (const int32_t *)a->col32, a->nnz, a->tile, c0.p, c16.p, flag);
+  SAMD_LAUNCH_CHECK(ctx);
+  int64_t host = 0;
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, &host));
+  if ((int)(host & 0xffffffff) != 0) return 0;  // some tile is too wide (random, power-law): 32-bit columns stay
+  a->col16 = c16.release();
+  a->tile_c0 = c0.release();
+  a->col16_state = 1;
+  return 0;
+}
+
 // the plan's two statistics: read back by the first product with a record, then cached
 template <class T>
 int plan_stats(futhark_context *ctx, const CsrBody<T> *a) {
@@ -667,7 +737,9 @@ int plan_stats(futhark_context *ctx, const CsrBody<T> *a) {
 }
 
 template <class T, class I>
-int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T *x, T *y) {
+int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T *x, T *y,
+               const int32_t *tile_c0 = nullptr) {
+  ctx->last_spmv_col_bytes = (int64_t)sizeof(I);
   int64_t algo = ctx->opt_spmv_algo;
   if (algo == 0) algo = 1;
   if (algo == 1) {
@@ -701,9 +773,14 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
 #define SAMD_SPMV_LAUNCH(INL, UU)                                                                                  \
   hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, INL, UU>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,   \
                      ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y,                      \
-                     (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force, (const uint16_t *)a->row_rel)
-    if (inl) { if (unroll == 6) SAMD_SPMV_LAUNCH(true, 6); else SAMD_SPMV_LAUNCH(true, 8); }
-    else { if (unroll == 6) SAMD_SPMV_LAUNCH(false, 6); else SAMD_SPMV_LAUNCH(false, 8); }
+                     (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force, (const uint16_t *)a->row_rel, tile_c0)
+    if constexpr (sizeof(I) == 2) {  // 16-bit columns exist for large records only
+      if (inl || !tile_c0) return set_error(ctx, "spmv: 16-bit columns on a record that has none");
+      if (unroll == 6) SAMD_SPMV_LAUNCH(false, 6); else SAMD_SPMV_LAUNCH(false, 8);
+    } else {
+      if (inl) { if (unroll == 6) SAMD_SPMV_LAUNCH(true, 6); else SAMD_SPMV_LAUNCH(true, 8); }
+      else { if (unroll == 6) SAMD_SPMV_LAUNCH(false, 6); else SAMD_SPMV_LAUNCH(false, 8); }
+    }
 #undef SAMD_SPMV_LAUNCH
     SAMD_LAUNCH_CHECK(ctx);
     if (a->ntiles > 1 && !(inl && a->spill_max <= kSpillInline)) {
@@ -714,6 +791,8 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     }
     return 0;
   }
+  if constexpr (sizeof(I) == 2) return set_error(ctx, "spmv: 16-bit columns are for the stream kernel only");
+  else {
   int lanes = algo == 2 ? 64 : (int)ctx->opt_spmv_lanes;
   if (lanes <= 0) lanes = 8;
   int64_t want = cdiv(a->n * lanes, kBlock);
@@ -734,6 +813,7 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
 #undef SAMD_VEC
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
+  }
 }
 
 // y[n] = A[n][m] x[m].  x and y are device pointers of the right lengths.
@@ -769,6 +849,9 @@ int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
     }
     return 0;
   }
+  if ((algo == 0 || algo == 1) && a->col16_state == 0) SAMD_TRY(col16_prepare<T>(ctx, a));
+  if ((algo == 0 || algo == 1) && a->col16_state == 1)
+    return spmv_typed<T, uint16_t>(ctx, a, (const uint16_t *)a->col16, x, y, (const int32_t *)a->tile_c0);
   if (a->col32) return spmv_typed<T, int32_t>(ctx, a, a->col32, x, y);
   return spmv_typed<T, int64_t>(ctx, a, a->col64, x, y);
 }

@@ -337,6 +337,46 @@ def test_smvm_two_pass_panels(ctx, dtype, geom):
             ctx.set_option(k, 0)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+def test_smvm_16_bit_columns_and_row_offsets_on_a_large_banded_record(ctx, dtype):
+    """Records of more than 4096 tiles read 16-bit tile-relative row offsets, and 16-bit tile-relative columns
+    when every tile spans fewer than 65536 columns (banded / stencil).  Against the oracle; bit-identical to the
+    32-bit-column kernel (same entries in the same order); one far-away entry makes a tile too wide and the
+    record keeps its 32-bit columns; empty rows, a row longer than a tile, rows crossing tile ends."""
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    n, hb = 300000, 8
+    i = np.arange(n, dtype=np.int64)
+    rs = np.repeat(i, 2 * hb + 1)
+    cs = rs + np.tile(np.arange(-hb, hb + 1, dtype=np.int64), n)
+    keep = (cs >= 0) & (cs < n) & (rs % 1000 != 7)                       # every 1000th row empty
+    rs, cs = rs[keep], cs[keep]
+    long_r = np.full(3000, 123456, np.int64)                             # one row longer than two tiles
+    long_c = 123456 - 1500 + np.arange(3000, dtype=np.int64)
+    rs, cs = np.concatenate([rs, long_r]), np.concatenate([cs, long_c])
+    vs = synth.uniform_values(31, len(rs), dtype)
+    x = synth.uniform_values(32, n, dtype)
+    A, Ao = M.sr.sparse(n, n, (rs, cs, vs)), O.sr_sparse(n, n, rs, cs, vs)
+    assert A.stored_dims()[2] > 4096 * 1024
+    y = M.sr.smvm(A, x).numpy()
+    assert ctx.get_option("spmv_last_col_bytes") == 2
+    close(y, O.sr_smvm(Ao, x), dtype)
+    ctx.set_option("spmv_col16", -1)
+    try:
+        A2 = M.sr.sparse(n, n, (rs, cs, vs))
+        y2 = M.sr.smvm(A2, x).numpy()
+        assert ctx.get_option("spmv_last_col_bytes") == 4
+    finally:
+        ctx.set_option("spmv_col16", 0)
+    assert y.tobytes() == y2.tobytes()
+    # one entry far from the band: its tile spans more than 65535 columns
+    rs3, cs3 = np.append(rs, 10), np.append(cs, n - 1)
+    vs3 = np.append(vs, vs[0])
+    A3, Ao3 = M.sr.sparse(n, n, (rs3, cs3, vs3)), O.sr_sparse(n, n, rs3, cs3, vs3)
+    y3 = M.sr.smvm(A3, x).numpy()
+    assert ctx.get_option("spmv_last_col_bytes") == 4
+    close(y3, O.sr_smvm(Ao3, x), dtype)
+
+
 @pytest.mark.parametrize("lanes", [0, 8])
 def test_smvm_long_runs_of_empty_rows(ctx, lanes):
     """Hundreds of thousands of empty rows before, between and after the stored ones: the tile that holds a
