@@ -523,7 +523,8 @@ void *sparse_amd_context_get_stream(struct futhark_context *ctx);
  * record is large enough, -1 never), "spmv_cblk" (column-blocked copy for wide records with flat column
  * popularity: 0 decided per record, W > 0 always, with W columns per block, -1 never).  "spmv_pb" (two-pass SpMV with the
  * x and y slices in LDS: 0 large skewed records of 4-byte values, 1 also flat column popularity, 2 always,
- * -1 never).  The per-record
+ * -1 never), "spmv_col16" (16-bit tile-relative columns for banded / stencil records: 0 decided per record,
+ * -1 never).  Read-only: "spmv_last_path", "spmv_last_col_bytes" (what the last product ran).  The per-record
  * choices are made at a record's first product.
  * Returns non-zero for an unknown key. */
 int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, int64_t value);
