@@ -178,6 +178,7 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         kern_ms = ev0.elapsed_time(ev1) / args.steps
+        ib = ctx.get_option("spmv_last_col_bytes")     # of the dominant kernel (the last product was local_smvm)
         m_loc = D.x_len
         # the x exchange alone (wall clock: the transfers run on the communicator's own stream)
         dist.barrier()
@@ -189,6 +190,7 @@ def main():
         ex_ms = (time.perf_counter() - tx) / args.steps * 1e3
     else:
         kern_ms = dev_ms
+        ib = ctx.get_option("spmv_last_col_bytes")
         m_loc = n_loc
         ex_ms = 0.0
 
@@ -208,9 +210,10 @@ def main():
         # algorithmic bytes of one launch on this rank, as resident on the device and read by the kernel:
         # entries (8 B value + 4 B i32 column index) + row offsets 2 B (tile-relative u16, row_rel) and y 8 B per
         # row + x 8 B per referenced column
-        ib = ctx.get_option("spmv_last_col_bytes")     # 2: 16-bit tile-relative columns (+ 4 B per 1024-entry tile)
+        # ib = 2: 16-bit tile-relative columns (+ 4 B per 1024-entry tile)
         ntl = (nnz + 1023) // 1024
-        alg_bytes = nnz * (8 + ib) + (ntl * 4 if ib == 2 else 0) + n_loc * 2 + n_loc * 8 + m_loc * 8
+        rb = 2 if ntl > 4096 else 8                    # small records (launch-bound path) read row_ptr itself
+        alg_bytes = nnz * (8 + ib) + (ntl * 4 if ib == 2 else 0) + n_loc * rb + n_loc * 8 + m_loc * 8
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -225,7 +228,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2D 5-point Laplacian CSR f64, %d^2 grid per GPU, SpMV (BASELINE configs[1])" % g,
-                       "rows_per_gpu": n_loc, "nnz_per_gpu": nnz, "nnz_total": nnz_glob, "col_idx_bytes": ib, "row_offset_bytes": 2,
+                       "rows_per_gpu": n_loc, "nnz_per_gpu": nnz, "nnz_total": nnz_glob, "col_idx_bytes": ib, "row_offset_bytes": rb,
                        "x_exchange": "none" if D is None else D.mode, "x_exchange_ms_alone": round(ex_ms, 5),
                        "assembly_s": round(asm_s, 4), "assembly_Mtriples_per_s": round(nnz0 / asm_s / 1e6, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
