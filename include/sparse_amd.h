@@ -257,7 +257,8 @@ SPARSE_AMD_DECL_ARRAY_2D(f64, double)
   /* sr.smvm (:134-146) into caller-owned storage, for loops that must not create an array per */ \
   /* product (the row-sharded multi-GPU step).  rows == NULL: y[i] = (A x)[i], y has A's n      */ \
   /* elements.  rows != NULL (n distinct indices into y): y[rows[i]] += (A x)[i] -- how a rank  */ \
-  /* adds the part of its rows that multiplies x entries received from other ranks.             */ \
+  /* adds the part of its rows that multiplies x entries received from other ranks (small       */ \
+  /* records: one launch, a row summed sub-wavefront-wise, i.e. in another order than smvm).    */ \
   int sparse_amd_csr_##TT##_smvm_into(struct futhark_context *ctx, struct futhark_##TT##_1d *y,   \
                                       const struct futhark_opaque_csr_##TT *a,                    \
                                       const struct futhark_##TT##_1d *x,                          \

@@ -258,6 +258,9 @@ int e_smvm_into(futhark_context *ctx, VA *y, const H *a, const VA *x, const futh
   if (rows->shape[0] != a->b->n) return set_error(ctx, "smvm_into: %lld row indices for %lld rows",
                                                   (long long)rows->shape[0], (long long)a->b->n);
   if (a->b->n == 0) return 0;
+  bool done = false;  // small records: one launch, no temporary
+  SAMD_TRY(spmv_rows_add_small<T>(ctx, a->b, x->data, y->data, rows->data, y->shape[0], &done));
+  if (done) return 0;
   Tmp<T> part(ctx);
   SAMD_TRY(part.get(a->b->n));
   SAMD_TRY(spmv<T>(ctx, a->b, x->data, part.p));

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(kBlock) void spmv_fixup_kernel(const int64_t *__res
 template <class T, class I, int LANES>
 __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(const int64_t *__restrict__ row_ptr,
                                                              const I *__restrict__ col, const T *__restrict__ val,
-                                                             const T *__restrict__ x, T *__restrict__ y, int64_t n) {
+                                                             const T *__restrict__ x, T *__restrict__ y, int64_t n,
+                                                             const int64_t *__restrict__ rows, int64_t ylen) {
   const int sub = threadIdx.x & (LANES - 1);
   const int64_t group = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LANES;
   const int64_t ngroups = (int64_t)gridDim.x * kBlock / LANES;
@@ -322,7 +323,13 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(const int64_t *__re
     for (int64_t q = rs + sub; q < re; q += LANES) acc = (T)(acc + (T)(val[q] * x[col[q]]));
 #pragma unroll
     for (int d = LANES / 2; d >= 1; d >>= 1) acc = (T)(acc + wshfl_xor(acc, d));
-    if (sub == 0) y[r] = acc;
+    if (sub == 0) {
+      if (!rows) y[r] = acc;
+      else {  // y[rows[r]] += (A x)[r]: distinct indices (the caller's contract), so no atomics
+        const int64_t d = rows[r];
+        if (d >= 0 && d < ylen) y[d] = (T)(y[d] + acc);
+      }
+    }
   }
 }
 
@@ -800,7 +807,8 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
   const unsigned grid = (unsigned)(want < cap ? (want > 0 ? want : 1) : cap);
 #define SAMD_VEC(L)                                                                                              \
   hipLaunchKernelGGL((spmv_vector_kernel<T, I, L>), dim3(grid), dim3(kBlock), 0, ctx->stream,                    \
-                     (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y, a->n)
+                     (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y, a->n, (const int64_t *)nullptr,       \
+                     (int64_t)0)
   switch (lanes) {
     case 2: SAMD_VEC(2); break;
     case 4: SAMD_VEC(4); break;
@@ -814,6 +822,35 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
   }
+}
+
+// y[rows[i]] += (A x)[i] in ONE launch, for the small records a row-sharded rank multiplies against received x
+// entries (a few thousand rows): sub-wavefront-per-row straight from global memory, indirect output.
+// Returns 1 if the record is not one of those (the caller then multiplies into a temporary and adds).
+template <class T>
+int spmv_rows_add_small(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y, const int64_t *rows,
+                        int64_t ylen, bool *done) {
+  *done = false;
+  if (a->nnz > (4 << 20) || a->n == 0 || ctx->opt_spmv_algo != 0) return 0;
+  *done = true;
+  if (a->nnz == 0) return 0;
+  const int64_t avg = a->nnz / a->n;
+  const int lanes = avg <= 2 ? 2 : (avg <= 12 ? 8 : 32);
+  const int64_t want = cdiv(a->n * lanes, kBlock), cap = (int64_t)ctx->num_cu * 32;
+  const unsigned grid = (unsigned)(want < cap ? (want > 0 ? want : 1) : cap);
+#define SAMD_VEC_ROWS(I, COL, L)                                                                                \
+  hipLaunchKernelGGL((spmv_vector_kernel<T, I, L>), dim3(grid), dim3(kBlock), 0, ctx->stream,                   \
+                     (const int64_t *)a->row_ptr, (const I *)COL, (const T *)a->vals, x, y, a->n, rows, ylen)
+  if (a->col32) {
+    if (lanes == 2) SAMD_VEC_ROWS(int32_t, a->col32, 2); else if (lanes == 8) SAMD_VEC_ROWS(int32_t, a->col32, 8);
+    else SAMD_VEC_ROWS(int32_t, a->col32, 32);
+  } else {
+    if (lanes == 2) SAMD_VEC_ROWS(int64_t, a->col64, 2); else if (lanes == 8) SAMD_VEC_ROWS(int64_t, a->col64, 8);
+    else SAMD_VEC_ROWS(int64_t, a->col64, 32);
+  }
+#undef SAMD_VEC_ROWS
+  SAMD_LAUNCH_CHECK(ctx);
+  return 0;
 }
 
 // y[n] = A[n][m] x[m].  x and y are device pointers of the right lengths.

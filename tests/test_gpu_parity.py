@@ -438,7 +438,10 @@ def test_smvm_into_caller_storage(ctx, dtype):
     M.sr.smvm_into(big, A, x, rows)
     expect = base.copy()
     expect[rows] = (expect[rows] + want).astype(NP[dtype])
-    assert np.array_equal(big.numpy(), expect)
+    close(big.numpy(), expect, dtype)      # small records take a one-launch kernel that sums a row in another order
+    untouched = np.ones(2 * n, bool)
+    untouched[rows] = False
+    assert np.array_equal(big.numpy()[untouched], base[untouched])
     with pytest.raises(SparseError):
         M.sr.smvm_into(ctx.array(np.zeros(n + 1, NP[dtype]), dtype), A, x)
     with pytest.raises(SparseError):
