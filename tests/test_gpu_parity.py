@@ -377,6 +377,27 @@ def test_smvm_16_bit_columns_and_row_offsets_on_a_large_banded_record(ctx, dtype
     close(y3, O.sr_smvm(Ao3, x), dtype)
 
 
+def test_smvm_large_record_whose_entries_fill_whole_tiles_with_trailing_empty_rows(ctx):
+    """Entry count an exact multiple of the 1024-entry tile, empty rows after the last entry (their start equals
+    the entry count: the one case in which a tile-relative row offset is 1024), empty rows in front, on a
+    record large enough for the 16-bit offsets and columns."""
+    O, M = Oracle("f64"), mk(ctx, "f64")
+    n0, per = 4200 * 128, 8                         # 4200 tiles exactly
+    lead, trail = 3, 100
+    i = np.arange(n0, dtype=np.int64)
+    rs = np.repeat(i + lead, per)
+    cs = np.repeat(i, per) + np.tile(np.arange(per, dtype=np.int64), n0)
+    n, m = n0 + lead + trail, n0 + per
+    vs = synth.uniform_values(41, len(rs), "f64")
+    x = synth.uniform_values(42, m, "f64")
+    A, Ao = M.sr.sparse(n, m, (rs, cs, vs)), O.sr_sparse(n, m, rs, cs, vs)
+    assert A.stored_dims()[2] == 4200 * 1024
+    y = M.sr.smvm(A, x).numpy()
+    assert ctx.get_option("spmv_last_col_bytes") == 2
+    close(y, O.sr_smvm(Ao, x), "f64")
+    assert np.all(y[:lead] == 0) and np.all(y[-trail:] == 0)
+
+
 @pytest.mark.parametrize("lanes", [0, 8])
 def test_smvm_long_runs_of_empty_rows(ctx, lanes):
     """Hundreds of thousands of empty rows before, between and after the stored ones: the tile that holds a
