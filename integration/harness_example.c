@@ -1,17 +1,23 @@
 /* harness_example.c -- a caller written ONLY against the generated-library convention.
  *
  * It runs the reference's own SpMV known-answer test (compressed_test.fut:49-55) through
- * futhark_entry_test_csr_smvm, then the same matrix through the typed f64 entries.
- * Linking it against libsparse_amd.so, or against the C library futhark generates from
- * compressed_test.fut + integration/sparse_entry.fut, needs no source change.
+ * futhark_entry_test_csr_smvm, then the same matrix through the typed f64 entries, then a
+ * store -> restore round trip of the opaque handle.  The header comes in by macro, so this one
+ * unchanged file builds against libsparse_amd.so or against the C library `futhark multicore
+ * --library` generates from compressed_test.fut + integration/sparse_entry.fut:
  *
  *   gcc -std=c99 -Iinclude integration/harness_example.c -Lsparse_amd/lib -lsparse_amd \
  *       -Wl,-rpath,$PWD/sparse_amd/lib -o integration/harness_example
+ *   gcc -std=c99 -I. -DHARNESS_HEADER='"sparse_entry.h"' integration/harness_example.c \
+ *       ./libsparse_ref.so -o harness_ref
  */
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "sparse_amd.h"
+#ifndef HARNESS_HEADER
+#define HARNESS_HEADER "sparse_amd.h"
+#endif
+#include HARNESS_HEADER
 
 static void die(struct futhark_context *ctx, const char *what) {
   char *e = futhark_context_get_error(ctx);
@@ -22,6 +28,7 @@ static void die(struct futhark_context *ctx, const char *what) {
 
 int main(void) {
   struct futhark_context_config *cfg = futhark_context_config_new();
+  futhark_context_config_set_num_threads(cfg, 16);  /* the multicore library's worker pool; a no-op on the GPU */
   struct futhark_context *ctx = futhark_context_new(cfg);
   char *e0 = futhark_context_get_error(ctx);
   if (e0) { fprintf(stderr, "context: %s\n", e0); return 2; }
@@ -53,6 +60,21 @@ int main(void) {
   if (futhark_values_f64_1d(ctx, fy, dy) != 0) die(ctx, "values f64");
   for (int i = 0; i < 5; i++)
     if (dy[i] != (double)want[i]) { fprintf(stderr, "f64 mismatch at %d\n", i); return 1; }
+
+  /* the opaque handle through its generated serialisers, and the product again on the restored one */
+  void *bytes = NULL;
+  size_t nbytes = 0;
+  if (futhark_store_opaque_csr_f64(ctx, A, &bytes, &nbytes) != 0) die(ctx, "store_opaque_csr_f64");
+  struct futhark_opaque_csr_f64 *A2 = futhark_restore_opaque_csr_f64(ctx, bytes);
+  if (!A2) die(ctx, "restore_opaque_csr_f64");
+  free(bytes);
+  struct futhark_f64_1d *fy2 = NULL;
+  if (futhark_entry_csr_f64_smvm(ctx, &fy2, A2, fx) != 0) die(ctx, "csr_f64_smvm (restored)");
+  if (futhark_values_f64_1d(ctx, fy2, dy) != 0) die(ctx, "values f64 (restored)");
+  for (int i = 0; i < 5; i++)
+    if (dy[i] != (double)want[i]) { fprintf(stderr, "restored f64 mismatch at %d\n", i); return 1; }
+  futhark_free_f64_1d(ctx, fy2);
+  futhark_free_opaque_csr_f64(ctx, A2);
 
   futhark_free_f64_1d(ctx, fy); futhark_free_f64_1d(ctx, fx); futhark_free_f64_1d(ctx, fvs);
   futhark_free_opaque_csr_f64(ctx, A);

@@ -245,6 +245,16 @@ class Matrix:
         self.ctx.check(f(self.ctx.h, ctypes.byref(ro), ctypes.byref(ci), ctypes.byref(va), self.h))
         return (self.ctx._out(ro, "i64"), self.ctx._out(ci, "i64"), self.ctx._out(va, self.dtype))
 
+    def store(self):
+        """The handle's bytes (futhark_store_opaque_*): n, m, row_off, col_idx, vals of the stored record."""
+        p, n = _VP(), ctypes.c_size_t()
+        f = getattr(self.ctx.L, "futhark_store_opaque_%s_%s" % (self.kind, self.dtype))
+        self.ctx.check(f(self.ctx.h, self.h, ctypes.byref(p), ctypes.byref(n)))
+        try:
+            return ctypes.string_at(p.value, n.value)
+        finally:
+            _libc.free(p)
+
     def free(self):
         if self.h and self.ctx.h:
             getattr(self.ctx.L, "futhark_free_opaque_%s_%s" % (self.kind, self.dtype))(self.ctx.h, self.h)
@@ -321,6 +331,15 @@ class _Module:
         r, c, v = _VP(), _VP(), _VP()
         self.ctx.check(self._f("coo")(self.ctx.h, ctypes.byref(r), ctypes.byref(c), ctypes.byref(v), self._chk(A)))
         return (self.ctx._out(r, "i64"), self.ctx._out(c, "i64"), self.ctx._out(v, self.t))
+
+    def restore(self, data):
+        """A matrix from Matrix.store() bytes (futhark_restore_opaque_*); the record is validated."""
+        f = getattr(self.ctx.L, "futhark_restore_opaque_%s_%s" % (self.kind, self.t))
+        f.restype = _VP
+        h = f(self.ctx.h, ctypes.c_char_p(bytes(data)))
+        if not h:
+            raise SparseError(self.ctx.error() or "restore failed")
+        return Matrix(self.ctx, h, self.kind, self.t)
 
     def add(self, A, B):
         out = _VP()

@@ -150,7 +150,8 @@ __global__ __launch_bounds__(kBlock) void plan_kernel(const int64_t *__restrict_
       atomicMax(reinterpret_cast<unsigned long long *>(&tile_lb[ntiles + 1]), (unsigned long long)(re - target));
   }
   const int64_t next = t + 1 == ntiles ? n : plan_lower_bound(row_ptr, n, target + tile);
-  atomicMax(reinterpret_cast<unsigned long long *>(&tile_lb[ntiles + 2]), (unsigned long long)(next - lo));
+  atomicMax(reinterpret_cast<unsigned long long *>(&tile_lb[ntiles + 2]),
+            (unsigned long long)(next - (lo > 0 ? lo - 1 : 0)));
 }
 
 constexpr int64_t kPlanTile = 1024;  // entries per tile; matches the SpMV kernels' TILE

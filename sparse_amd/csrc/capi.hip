@@ -322,6 +322,101 @@ int e_from_fields(futhark_context *ctx, H **out, int64_t n, int64_t m, const fut
   return wrap_body(ctx, out, b);
 }
 
+// ---- store / restore of the opaque sr / sc values (the serialisers `futhark c --library` generates for
+// every opaque type; the byte format is the library's own).  Layout: "SAMDCSR1", 8-byte element tag,
+// int64 n, m, nnz of the STORED record (for a csc handle: of the transpose, compressed.fut:226), then
+// row_off[n] i64 (inclusive, :94), col_idx[nnz] i64, vals[nnz].
+struct StoreHeader {
+  char magic[8];
+  char tag[8];
+  int64_t n, m, nnz;
+};
+
+template <class T> struct TagOf;
+template <> struct TagOf<double> { static const char *name() { return "f64"; } };
+template <> struct TagOf<float> { static const char *name() { return "f32"; } };
+template <> struct TagOf<int32_t> { static const char *name() { return "i32"; } };
+
+template <class T, class H>
+int e_store(futhark_context *ctx, const H *a, void **p, size_t *n) {
+  const CsrBody<T> *b = a->b;
+  const size_t bytes = sizeof(StoreHeader) + sizeof(int64_t) * (size_t)(b->n + b->nnz) + sizeof(T) * (size_t)b->nnz;
+  if (n) *n = bytes;
+  if (!p) return 0;  // size query
+  Tmp<int64_t> ro(ctx), ci(ctx);
+  Tmp<T> va(ctx);
+  SAMD_TRY(ro.get(b->n));
+  SAMD_TRY(ci.get(b->nnz));
+  SAMD_TRY(va.get(b->nnz));
+  SAMD_TRY(to_fields<T>(ctx, b, ro.p, ci.p, va.p));
+  char *out = (char *)*p;
+  const bool mine = out == nullptr;
+  if (mine) {
+    out = (char *)malloc(bytes);
+    if (!out) return set_error(ctx, "store: host allocation of %zu bytes failed", bytes);
+  }
+  StoreHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "SAMDCSR1", 8);
+  strncpy(h.tag, TagOf<T>::name(), sizeof h.tag - 1);
+  h.n = b->n; h.m = b->m; h.nnz = b->nnz;
+  memcpy(out, &h, sizeof h);
+  char *q = out + sizeof h;
+  hipError_t e = hipSuccess;
+  if (b->n > 0) e = hipMemcpyAsync(q, ro.p, sizeof(int64_t) * (size_t)b->n, hipMemcpyDeviceToHost, ctx->stream);
+  q += sizeof(int64_t) * (size_t)b->n;
+  if (e == hipSuccess && b->nnz > 0)
+    e = hipMemcpyAsync(q, ci.p, sizeof(int64_t) * (size_t)b->nnz, hipMemcpyDeviceToHost, ctx->stream);
+  q += sizeof(int64_t) * (size_t)b->nnz;
+  if (e == hipSuccess && b->nnz > 0)
+    e = hipMemcpyAsync(q, va.p, sizeof(T) * (size_t)b->nnz, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (mine) free(out);
+    return set_error(ctx, "store: copy to host failed: %s", hipGetErrorString(e));
+  }
+  *p = out;
+  return 0;
+}
+
+template <class T, class H>
+H *e_restore(futhark_context *ctx, const void *p) {
+  if (!p) { set_error(ctx, "restore: null buffer"); return nullptr; }
+  StoreHeader h;
+  memcpy(&h, p, sizeof h);
+  if (memcmp(h.magic, "SAMDCSR1", 8) != 0) { set_error(ctx, "restore: not a stored sparse_amd matrix"); return nullptr; }
+  h.tag[sizeof h.tag - 1] = 0;
+  if (strcmp(h.tag, TagOf<T>::name()) != 0) {
+    set_error(ctx, "restore: stored element type is %s, wanted %s", h.tag, TagOf<T>::name());
+    return nullptr;
+  }
+  if (h.n < 0 || h.m < 0 || h.nnz < 0) { set_error(ctx, "restore: negative size in header"); return nullptr; }
+  Tmp<int64_t> ro(ctx), ci(ctx);
+  Tmp<T> va(ctx);
+  if (ro.get(h.n) != 0 || ci.get(h.nnz) != 0 || va.get(h.nnz) != 0) return nullptr;
+  const char *q = (const char *)p + sizeof h;
+  hipError_t e = hipSuccess;
+  if (h.n > 0) e = hipMemcpyAsync(ro.p, q, sizeof(int64_t) * (size_t)h.n, hipMemcpyHostToDevice, ctx->stream);
+  q += sizeof(int64_t) * (size_t)h.n;
+  if (e == hipSuccess && h.nnz > 0)
+    e = hipMemcpyAsync(ci.p, q, sizeof(int64_t) * (size_t)h.nnz, hipMemcpyHostToDevice, ctx->stream);
+  q += sizeof(int64_t) * (size_t)h.nnz;
+  if (e == hipSuccess && h.nnz > 0)
+    e = hipMemcpyAsync(va.p, q, sizeof(T) * (size_t)h.nnz, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the caller may release p on return
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error(ctx, "restore: copy to device failed: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  CsrBody<T> *b = nullptr;
+  if (from_fields<T>(ctx, h.n, h.m, ro.p, ci.p, va.p, h.nnz, &b) != 0) return nullptr;  // validates the record
+  H *out = nullptr;
+  wrap_body(ctx, &out, b);
+  return out;
+}
+
 // ---- mono (S/mono.fut): typed entry bodies
 template <class H, class T>
 int m_wrap(H **out, MonoBody<T> *b) {
@@ -460,6 +555,9 @@ void futhark_context_config_free(struct futhark_context_config *cfg) { delete cf
 void futhark_context_config_set_debugging(struct futhark_context_config *cfg, int flag) { cfg->debugging = flag; }
 void futhark_context_config_set_profiling(struct futhark_context_config *cfg, int flag) { cfg->profiling = flag; }
 void futhark_context_config_set_logging(struct futhark_context_config *cfg, int flag) { cfg->logging = flag; }
+// Generated by the multicore back end (worker pool size).  Accepted and recorded; a GPU context has no
+// worker pool, so it changes nothing -- a harness written for `futhark multicore --library` links and runs.
+void futhark_context_config_set_num_threads(struct futhark_context_config *cfg, int n) { cfg->num_threads = n; }
 void futhark_context_config_set_device(struct futhark_context_config *cfg, const char *s) {
   if (!s) return;
   if (s[0] == '#') s++;
@@ -677,6 +775,22 @@ SAMD_ARRAY_2D(f64, double)
 #define SAMD_MATRIX(TT, CT)                                                                                   \
   int futhark_free_opaque_csr_##TT(CTX, CSR(TT) * o) { ENTER(ctx); return free_handle(ctx, o); }            \
   int futhark_free_opaque_csc_##TT(CTX, CSC(TT) * o) { ENTER(ctx); return free_handle(ctx, o); }            \
+  int futhark_store_opaque_csr_##TT(CTX, const CSR(TT) * obj, void **p, size_t *n) {                          \
+    ENTER(ctx);                                                                                             \
+    return e_store<CT>(ctx, obj, p, n);                                                                       \
+  }                                                                                                           \
+  int futhark_store_opaque_csc_##TT(CTX, const CSC(TT) * obj, void **p, size_t *n) {                          \
+    ENTER(ctx);                                                                                             \
+    return e_store<CT>(ctx, obj, p, n);                                                                       \
+  }                                                                                                           \
+  CSR(TT) * futhark_restore_opaque_csr_##TT(CTX, const void *p) {                                             \
+    ENTER(ctx);                                                                                             \
+    return e_restore<CT, CSR(TT)>(ctx, p);                                                                    \
+  }                                                                                                           \
+  CSC(TT) * futhark_restore_opaque_csc_##TT(CTX, const void *p) {                                             \
+    ENTER(ctx);                                                                                             \
+    return e_restore<CT, CSC(TT)>(ctx, p);                                                                    \
+  }                                                                                                           \
   int futhark_entry_csr_##TT##_sparse(CTX, CSR(TT) * *out0, const int64_t n, const int64_t m, I64A *rs,       \
                                       I64A *cs, const A1(TT) * vs) {                                          \
     ENTER(ctx);                                                                                             \

@@ -92,6 +92,7 @@ class Pool {
 struct futhark_context_config {
   int device = 0;
   int debugging = 0, profiling = 0, logging = 0;
+  int num_threads = 0;  // multicore back end's knob: recorded, unused (no CPU path)
 };
 
 struct futhark_context {
@@ -244,7 +245,7 @@ struct CsrBody {
   mutable uint16_t *row_rel = nullptr;  // [n + 1] row starts relative to their tile (spmv.hpp: row_rel_kernel); built lazily
   // plan statistics (tile_lb[ntiles+1], [ntiles+2]), read back once by the first product
   mutable int64_t spill_max = -1;      // longest first spill
-  mutable int64_t max_tile_rows = -1;  // most rows starting in one tile
+  mutable int64_t max_tile_rows = -1;  // most rows one tile's block visits (max over tiles of the kernels' nrows64)
   // hot-column renumbering for gather-bound SpMV (spmv.hpp, "reorder"); built lazily, owned by the record
   mutable int reorder_state = 0;   // 0 undecided, 1 active, -1 rejected
   mutable int32_t *col_hot = nullptr;    // [nnz] rank of each entry's column by popularity

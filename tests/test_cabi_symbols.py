@@ -41,6 +41,23 @@ def test_reference_entry_names_present():
         assert "futhark_entry_" + w in syms
 
 
+def test_generated_api_surface_of_the_multicore_reference_library():
+    # what a harness for `futhark multicore --library` calls besides the entries: the worker-pool
+    # knob and the serialisers of the opaque sr / sc types
+    syms = declared_symbols()
+    assert "futhark_context_config_set_num_threads" in syms
+    for kind in ("csr", "csc"):
+        for t in ("f64", "f32", "i32"):
+            assert "futhark_store_opaque_%s_%s" % (kind, t) in syms
+            assert "futhark_restore_opaque_%s_%s" % (kind, t) in syms
+    from sparse_amd.compressed import library_path
+    lib = ctypes.CDLL(library_path())
+    lib.futhark_context_config_new.restype = ctypes.c_void_p
+    cfg = ctypes.c_void_p(lib.futhark_context_config_new())
+    lib.futhark_context_config_set_num_threads(cfg, 16)      # host-only call: accepted without a GPU
+    lib.futhark_context_config_free(cfg)
+
+
 def test_product_never_touches_the_oracle():
     # the oracle is test infrastructure: nothing under sparse_amd/ may import, link or load it
     bad = []

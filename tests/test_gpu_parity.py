@@ -428,6 +428,37 @@ def test_smvm_long_runs_of_empty_rows(ctx, lanes):
         ctx.set_option("spmv_lanes", 0)
 
 
+@pytest.mark.parametrize("tiles", [8, 4200])
+def test_smvm_and_smm_exactly_2048_rows_start_in_every_tile(ctx, tiles):
+    """One entry in every odd row: 2048 rows start in every 1024-entry tile, and with the candidate head row in
+    front of them a tile's block visits 2049 -- one past the limit of the row-driven path, so every tile but
+    the first takes the entry-driven path that writes no zeros.  The host must then have cleared the result
+    (the plan statistic and the kernels' row count share one definition).  Results go into storage that held
+    sevens; 8 tiles = the launch-bound variant, 4200 = the large-record variant.  Against the oracle."""
+    n = tiles * 2048
+    rs = np.arange(1, n, 2, dtype=np.int64)
+    cs = (rs * 7) % 1000
+    m = 1000
+    for dtype in ("f64", "i32"):
+        O, M = Oracle(dtype), mk(ctx, dtype)
+        v = synth.uniform_values(61, len(rs), dtype)
+        x = synth.uniform_values(62, m, dtype)
+        A, Ao = M.sr.sparse(n, m, (rs, cs, v)), O.sr_sparse(n, m, rs, cs, v)
+        assert A.stored_dims()[2] == tiles * 1024
+        y = ctx.array(np.full(n, 7, NP[dtype]), dtype)
+        M.sr.smvm_into(y, A, x)
+        want = O.sr_smvm(Ao, x)
+        close(y.numpy(), want, dtype)
+        assert np.all(y.numpy()[0::2] == 0)
+        k = 4
+        B = synth.uniform_values(63, m * k, dtype).reshape(m, k)
+        junk = ctx.array(np.full((n, k), 7, NP[dtype]), dtype, 2)   # the pool hands this block to the product
+        junk.free()
+        C = M.sr.smm(A, B).numpy()
+        close(C, O.sr_smm(Ao, B), dtype)
+        assert np.all(C[0::2] == 0)
+
+
 def test_smvm_empty_and_shape_errors(ctx):
     from sparse_amd.compressed import SparseError
     M = mk(ctx, "f64")
@@ -632,6 +663,54 @@ def test_from_fields_roundtrip(ctx):
     bad_ro[10] = bad_ro[9] - 1 if bad_ro[9] > 0 else 10**9
     with pytest.raises(SparseError):
         M.sr.from_fields(300, 400, bad_ro, Ao["col_idx"], Ao["vals"])
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+def test_store_restore_opaque_roundtrip(ctx, dtype):
+    """futhark_store_opaque_* -> futhark_restore_opaque_* through the raw C ABI: the restored handle's
+    fields are bit-equal (also for a csc handle, an empty record and the size-query / caller-buffer forms),
+    and malformed bytes are refused."""
+    from sparse_amd.compressed import SparseError
+    M, O = mk(ctx, dtype), Oracle(dtype)
+    n, m = 700, 900
+    r, c, v = random_coo(n, m, 9000, dtype, seed=77)
+    A = M.sr.sparse(n, m, (r, c, v))
+    blob = A.store()
+    A2 = M.sr.restore(blob)
+    for a, b in zip(fields(A), fields(A2)):
+        assert np.array_equal(a, b)
+    assert_same_record(A2, O.sr_sparse(n, m, r, c, v))
+    x = synth.uniform_values(5, m, dtype)
+    assert np.array_equal(M.sr.smvm(A2, x).numpy(), M.sr.smvm(A, x).numpy())
+    # csc handle: the stored record is that of the transpose
+    B = M.sc.sparse(n, m, (r, c, v))
+    B2 = M.sc.restore(B.store())
+    assert B2.stored_dims() == B.stored_dims() == (m, n, B.stored_dims()[2])
+    for a, b in zip(fields(B), fields(B2)):
+        assert np.array_equal(a, b)
+    # empty record
+    Z2 = M.sr.restore(M.sr.zero(3, 4).store())
+    assert Z2.stored_dims() == (3, 4, 0)
+    # size query (p == NULL) and a caller-provided buffer
+    L = ctx.L
+    f = getattr(L, "futhark_store_opaque_csr_" + dtype)
+    size = ctypes.c_size_t()
+    assert f(ctx.h, A.h, None, ctypes.byref(size)) == 0 and size.value == len(blob)
+    buf = ctypes.create_string_buffer(size.value)
+    pbuf = ctypes.c_void_p(ctypes.addressof(buf))
+    assert f(ctx.h, A.h, ctypes.byref(pbuf), ctypes.byref(size)) == 0
+    assert pbuf.value == ctypes.addressof(buf) and buf.raw == blob
+    # refused: wrong magic, wrong element type, a record that is not normalised
+    with pytest.raises(SparseError):
+        M.sr.restore(b"X" + blob[1:])
+    other = mk(ctx, "f32" if dtype != "f32" else "f64")
+    with pytest.raises(SparseError):
+        other.sr.restore(blob)
+    bad = bytearray(blob)
+    hdr = 8 + 8 + 24
+    bad[hdr:hdr + 8] = np.int64(10**6).tobytes()      # row_off[0] beyond nnz
+    with pytest.raises(SparseError):
+        M.sr.restore(bytes(bad))
 
 
 def test_wide_col_option_keeps_parity(ctx):
