@@ -378,6 +378,15 @@ class _SR(_Module):
         self.ctx.check(f(self.ctx.h, y.h, self._chk(A), v.h, rows.h if rows is not None else None))
         return y
 
+    def smvm_into_noalloc(self, y, A, v):
+        """y = A v through the entry point that allocates nothing (sparse_amd_csr_*_smvm_into_noalloc);
+        y and v must already be DeviceArray objects or torch CUDA tensors."""
+        y = self.ctx.array(y, self.t)
+        v = self.ctx.array(v, self.t)
+        f = getattr(self.ctx.L, "sparse_amd_csr_%s_smvm_into_noalloc" % self.t)
+        self.ctx.check(f(self.ctx.h, y.h, self._chk(A), v.h))
+        return y
+
     def smm(self, A, B):
         """Sparse x dense panel, C[:,j] = smvm A B[:,j] (build-defined; see include/sparse_amd.h)."""
         B = self.ctx.array(B, self.t, 2)

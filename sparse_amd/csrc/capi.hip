@@ -15,6 +15,14 @@
 
 using namespace samd;
 
+// ---------------------------------------------------------------- static scratch
+// Device memory that exists without any allocation call, for the one entry point that must allocate nothing
+// (sparse_amd_csr_*_smvm_into_noalloc).  Every GPU the library runs on holds its own copy of this array, at its
+// own address, until the process ends.  In host code the array's name is only a stand-in: the address a kernel
+// may use comes from hipGetSymbolAddress with the device current (futhark_context_new keeps it in the context).
+constexpr size_t kStaticScratchBytes = (size_t)4 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 // ---------------------------------------------------------------- records
 struct futhark_i64_1d : DevArray<int64_t, 1> {};
 struct futhark_i32_1d : DevArray<int32_t, 1> {};
@@ -268,6 +276,18 @@ int e_smvm_into(futhark_context *ctx, VA *y, const H *a, const VA *x, const futh
                      (const T *)part.p, (const int64_t *)rows->data, a->b->n, y->shape[0], y->data);
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+template <class T, class H, class VA>
+int e_smvm_into_noalloc(futhark_context *ctx, VA *y, const H *a, const VA *x) {
+  if (x->shape[0] != a->b->m) return set_error(ctx, "smvm_into_noalloc: vector length %lld does not match matrix (%lld)",
+                                               (long long)x->shape[0], (long long)a->b->m);
+  if (y->shape[0] != a->b->n) return set_error(ctx, "smvm_into_noalloc: result has %lld elements, matrix has %lld rows",
+                                               (long long)y->shape[0], (long long)a->b->n);
+  size_t room = kStaticScratchBytes;  // test override: pretend the array is smaller (never larger)
+  if (ctx->opt_noalloc_scratch_bytes > 0 && (size_t)ctx->opt_noalloc_scratch_bytes < room)
+    room = (size_t)ctx->opt_noalloc_scratch_bytes;
+  return spmv_noalloc<T>(ctx, a->b, x->data, y->data, ctx->static_scratch, room);
 }
 
 template <class T, class H, class A2>
@@ -588,6 +608,16 @@ struct futhark_context *futhark_context_new(struct futhark_context_config *cfg) 
     set_error(ctx, "context initialisation failed: %s", hipGetErrorString(hipGetLastError()));
     return ctx;
   }
+  {
+    void *sp = nullptr;
+    const hipError_t es = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));  // this device's copy (the device is current)
+    if (es != hipSuccess) {
+      (void)hipGetLastError();
+      set_error(ctx, "context initialisation failed: hipGetSymbolAddress(scratch): %s", hipGetErrorString(es));
+      return ctx;
+    }
+    ctx->static_scratch = sp;
+  }
   ctx->stream = ctx->own_stream;
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (ctx->logging) fprintf(stderr, "[sparse_amd] device #%d %s (%s), %d CUs\n", ctx->device, prop.name,
@@ -664,6 +694,7 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_pb_lines")) ctx->opt_spmv_pb_lines = value;
   else if (!strcmp(key, "spmv_pb_entries")) ctx->opt_spmv_pb_entries = value;
   else if (!strcmp(key, "ablate")) ctx->opt_ablate = value;
+  else if (!strcmp(key, "noalloc_scratch_bytes")) ctx->opt_noalloc_scratch_bytes = value;
   else return set_error(ctx, "unknown option '%s'", key);
   return 0;
 }
@@ -935,6 +966,10 @@ SAMD_ARRAY_2D(f64, double)
   int sparse_amd_csr_##TT##_smvm_into(CTX, A1(TT) * y, const CSR(TT) * a, const A1(TT) * x, I64A *rows) {     \
     ENTER(ctx);                                                                                             \
     return e_smvm_into<CT>(ctx, y, a, x, rows);                                                               \
+  }                                                                                                           \
+  int sparse_amd_csr_##TT##_smvm_into_noalloc(CTX, A1(TT) * y, const CSR(TT) * a, const A1(TT) * x) {         \
+    ENTER(ctx);                                                                                             \
+    return e_smvm_into_noalloc<CT>(ctx, y, a, x);                                                             \
   }
 
 SAMD_MATRIX(f64, double)

@@ -108,6 +108,8 @@ struct futhark_context {
   // pinned staging for small device->host reads (counts, flags)
   int64_t *h_small = nullptr;  // 16 int64
   int64_t *d_small = nullptr;  // 16 int64
+  // this device's copy of the library's static scratch array (capi.hip), looked up at context creation
+  void *static_scratch = nullptr;
   // options (sparse_amd_context_set_option)
   int64_t opt_spmv_algo = 0;
   int64_t opt_spmv_lanes = 0;
@@ -120,6 +122,7 @@ struct futhark_context {
   int64_t opt_spmv_pb_rows = 0, opt_spmv_pb_lines = 0, opt_spmv_pb_entries = 0;  // test overrides: rows per panel,
                                                                                  // 32-column lines per block, entries per panel
   int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
+  int64_t opt_noalloc_scratch_bytes = 0;  // tests: treat the static scratch array as this small (0 = its real size)
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
   // statistics for futhark_context_report
   int64_t n_entries = 0;

@@ -743,12 +743,17 @@ int plan_stats(futhark_context *ctx, const CsrBody<T> *a) {
   return 0;
 }
 
+// head_override: the array that receives the tiles' head sums instead of the record's own (spmv_noalloc);
+// with it nothing may be allocated here either, so a record without row_rel takes the INLINE kernels
+// (they read row_ptr itself and are valid at any size, just slower on large records).
 template <class T, class I>
 int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T *x, T *y,
-               const int32_t *tile_c0 = nullptr) {
+               const int32_t *tile_c0 = nullptr, T *head_override = nullptr) {
   ctx->last_spmv_col_bytes = (int64_t)sizeof(I);
+  const bool noalloc = head_override != nullptr;
+  T *const head = noalloc ? head_override : a->head;
   int64_t algo = ctx->opt_spmv_algo;
-  if (algo == 0) algo = 1;
+  if (algo == 0 || noalloc) algo = 1;
   if (algo == 1) {
     if (a->tile != kSpmvTile) return set_error(ctx, "spmv: plan tile mismatch");
     int force = (int)ctx->opt_spmv_lanes;
@@ -756,7 +761,7 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     // Small records are launch-bound: there the owner tile finishes short spills itself and the fix-up
     // launch is dropped when no row spills far.  Large records keep the fix-up launch (measured faster:
     // C2 0.238 vs 0.244 ms), so nothing is read back for them.
-    const bool inl = a->ntiles > 1 && a->ntiles <= kInlineMaxTiles;
+    const bool inl = (a->ntiles > 1 && a->ntiles <= kInlineMaxTiles) || (noalloc && !a->row_rel);
     SAMD_TRY(plan_stats(ctx, a));
     if (a->max_tile_rows > kDenseRowsMax)  // some tile takes the many-empty-rows path, which writes no zeros
       SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));
@@ -780,7 +785,7 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
 #define SAMD_SPMV_LAUNCH(INL, UU)                                                                                  \
   hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, INL, UU>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,   \
                      ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y,                      \
-                     (const int64_t *)a->tile_lb, a->head, a->nnz, a->ntiles, force, (const uint16_t *)a->row_rel, tile_c0)
+                     (const int64_t *)a->tile_lb, head, a->nnz, a->ntiles, force, (const uint16_t *)a->row_rel, tile_c0)
     if constexpr (sizeof(I) == 2) {  // 16-bit columns exist for large records only
       if (inl || !tile_c0) return set_error(ctx, "spmv: 16-bit columns on a record that has none");
       if (unroll == 6) SAMD_SPMV_LAUNCH(false, 6); else SAMD_SPMV_LAUNCH(false, 8);
@@ -793,7 +798,7 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     if (a->ntiles > 1 && !(inl && a->spill_max <= kSpillInline)) {
       hipLaunchKernelGGL((spmv_fixup_kernel<T, kSpmvTile>), dim3((unsigned)cdiv(a->ntiles - 1, kBlock)), dim3(kBlock),
                          0, ctx->stream, (const int64_t *)a->row_ptr, (const int64_t *)a->tile_lb,
-                         (const T *)a->head, y, a->ntiles, inl);
+                         (const T *)head, y, a->ntiles, inl);
       SAMD_LAUNCH_CHECK(ctx);
     }
     return 0;
@@ -851,6 +856,30 @@ int spmv_rows_add_small(futhark_context *ctx, const CsrBody<T> *a, const T *x, T
 #undef SAMD_VEC_ROWS
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
+}
+
+// y = A x without allocating anything (capi.hip: sparse_amd_csr_*_smvm_into_noalloc): the one-pass stream
+// kernel on whatever the record already holds, the tiles' head sums in `scratch` (the library's static device
+// array) instead of the record's head[].  Nothing is built lazily here: 16-bit columns and row offsets are used
+// if an earlier ordinary product made them, the gather-bound paths (renumbering, column blocks, two passes) never.
+template <class T>
+int spmv_noalloc(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y, void *scratch, size_t scratch_bytes) {
+  if (a->n == 0) return 0;
+  if (a->nnz == 0) {
+    SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));
+    return 0;
+  }
+  if (!scratch) return set_error(ctx, "smvm_into_noalloc: the static scratch array is not available on this device");
+  if ((size_t)a->ntiles * sizeof(T) > scratch_bytes)
+    return set_error(ctx, "smvm_into_noalloc: record of %lld entries needs %zu bytes of scratch, the static array holds %zu "
+                     "(at most %zu entries for this element type)", (long long)a->nnz, (size_t)a->ntiles * sizeof(T),
+                     scratch_bytes, scratch_bytes / sizeof(T) * (size_t)kSpmvTile);
+  ctx->last_spmv_path = 0;
+  T *head = reinterpret_cast<T *>(scratch);
+  if (a->col16_state == 1 && a->row_rel && a->ntiles > kInlineMaxTiles)
+    return spmv_typed<T, uint16_t>(ctx, a, (const uint16_t *)a->col16, x, y, (const int32_t *)a->tile_c0, head);
+  if (a->col32) return spmv_typed<T, int32_t>(ctx, a, a->col32, x, y, nullptr, head);
+  return spmv_typed<T, int64_t>(ctx, a, a->col64, x, y, nullptr, head);
 }
 
 // y[n] = A[n][m] x[m].  x and y are device pointers of the right lengths.
