@@ -264,7 +264,13 @@ class ExchangePlan:
         own = x_ext[self.own_offset:self.own_offset + self.n_own]
         if self.mode == "allgather":
             if self.equal_slices:
-                dist.all_gather_into_tensor(x_ext, own.clone())
+                # the collective's input may not alias its output: a staging buffer made once per x_ext (no
+                # allocation per product), filled by a device copy on the same stream
+                key = (x_ext.data_ptr(), x_ext.dtype, tuple(x_ext.shape))
+                if getattr(self, "_stage_key", None) != key:
+                    self._stage, self._stage_key = torch.empty_like(own), key
+                self._stage.copy_(own)
+                dist.all_gather_into_tensor(x_ext, self._stage)
                 return x_ext
             ops = []
             for p in range(self.world):
@@ -320,6 +326,13 @@ class DistCsr:
     def __init__(self, M, plan, A, n_loc, torch_dtype, A_gh=None, rows_g=None):
         self.M, self.plan, self.A, self.n_loc = M, plan, A, n_loc
         self.A_gh, self.rows_g = A_gh, rows_g
+        # One stream for everything a product does.  The library runs on its context's stream, torch ops and
+        # the RCCL transfers (whose wait() orders torch's current stream only) on torch's: if they differed the
+        # product on received entries could start before they have landed.  So the context adopts torch's
+        # current stream here (it first drains its own); nothing is left to the caller.
+        import torch as _torch
+        if _torch.cuda.is_available() and str(plan.device).startswith("cuda"):
+            M.ctx.set_stream(_torch.cuda.current_stream(_torch.device(plan.device)).cuda_stream)
         self.mode = plan.mode
         self.x_len = plan.x_len if A_gh is None else plan.n_own
         self.x_ext, self.x_own = plan.new_x(torch_dtype)
@@ -338,19 +351,24 @@ class DistCsr:
     @classmethod
     def from_local_coo(cls, M, dist, n_glob, m_glob, row_lo, row_hi, rs, cs, vs, force_mode=None, split=True):
         """rs/cs/vs: this rank's COO triples (torch CUDA tensors, GLOBAL indices, rows in
-        [row_lo,row_hi)).  x is partitioned like the rows (square matrices)."""
+        [row_lo,row_hi)).  Square matrices: x is partitioned like the rows.  Rectangular ones (n_glob !=
+        m_glob): x is cut into world equal slices (the last takes the remainder)."""
         import torch
-        assert n_glob == m_glob, "x is partitioned like the rows: square matrices only"
         dev = rs.device
         world = dist.get_world_size() if dist is not None else 1
-        mine = torch.tensor([row_hi], dtype=torch.int64, device=dev)
-        his = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        if world > 1:
-            dist.all_gather(his, mine)
+        rank = dist.get_rank() if dist is not None else 0
+        if n_glob == m_glob:
+            mine = torch.tensor([row_hi], dtype=torch.int64, device=dev)
+            his = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            if world > 1:
+                dist.all_gather(his, mine)
+            else:
+                his = [mine]
+            bounds = [0] + [int(h.item()) for h in his]
+            assert bounds[-1] == m_glob and bounds[rank] == row_lo
         else:
-            his = [mine]
-        bounds = [0] + [int(h.item()) for h in his]
-        assert bounds[-1] == m_glob and bounds[(dist.get_rank() if dist is not None else 0)] == row_lo
+            per = -(-m_glob // world)
+            bounds = [min(k * per, m_glob) for k in range(world)] + [m_glob]
         needed = torch.unique(cs)
         plan = ExchangePlan(dist, bounds, needed, dev, force_mode)
         del needed

@@ -197,6 +197,48 @@ def random_uniform_coo_device(n, m, nnz0, device, dtype="f64", seed=42):
     return r, c, v
 
 
+def _lsr(z, k):
+    """Logical right shift of an int64 tensor holding a uint64 bit pattern."""
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def splitmix64_device(seed, start, count, device):
+    """splitmix64(seed, index) for index = start .. start+count-1 as int64 bit patterns (torch has no uint64
+    arithmetic; int64 multiplication wraps the same way).  Bit-identical to the numpy splitmix64 above."""
+    import torch
+
+    def c(v):   # uint64 constant as the int64 with the same bits
+        v &= 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v >= (1 << 63) else v
+    idx = torch.arange(start + 1, start + 1 + count, dtype=torch.int64, device=device)
+    z = idx * c(0x9E3779B97F4A7C15) + c(seed)
+    z = (z ^ _lsr(z, 30)) * c(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * c(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def _umod(z, n):
+    """(uint64 bit pattern z) mod n for 0 < n < 2^62, in int64 arithmetic: z = 2 h + b."""
+    return ((_lsr(z, 1) % n) * 2 + (z & 1)) % n
+
+
+def random_uniform_coo_counter_device(n, m, start, count, device, dtype="f64", seed=42, integer_values=False):
+    """Triples start .. start+count-1 of random_uniform_coo(n, m, *, dtype, seed), generated on the device
+    from the counter PRNG: any rank can produce any slice of the same global list (the C5 leg of bench.py).
+    integer_values: values in -9..9 as floats (every sum exact in any order: the parity gate's data);
+    otherwise the same uniform [0.5, 1.5) values as the host generator, bit for bit."""
+    import torch
+    r = _umod(splitmix64_device(seed, start, count, device), n)
+    c = _umod(splitmix64_device(seed + 1, start, count, device), m)
+    z = splitmix64_device(seed + 2, start, count, device)
+    tdt = {"f64": torch.float64, "f32": torch.float32}[dtype]
+    if integer_values:
+        v = (_umod(z, 19) - 9).to(tdt)
+    else:
+        v = (_lsr(z, 11).to(torch.float64) * (1.0 / (1 << 53)) + 0.5).to(tdt)
+    return r, c, v
+
+
 def rmat_coo_device(scale, edge_factor, device, dtype="f32", seed=42, probs=(0.57, 0.19, 0.19, 0.05)):
     """C3 shape on the device: RMAT, one quadrant draw per bit level."""
     import torch

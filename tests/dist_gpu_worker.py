@@ -81,6 +81,22 @@ def main():
     for rep in range(3):
         y = D2.smvm(t((rep + 1) * x2[lo:hi], dev)).cpu().numpy()
         assert np.array_equal(y, (rep + 1) * y2[lo:hi]), ("banded smvm", rep)
+    # ---- rectangular matrix (x cut into equal slices, rows by the triple histogram): both exchange modes
+    n3, m3, k3 = 9000, 5000, 120000
+    idx = np.arange(k3, dtype=np.uint64)
+    r3 = (synth.splitmix64(41, idx) % np.uint64(n3)).astype(np.int64)
+    c3 = (synth.splitmix64(42, idx) % np.uint64(m3)).astype(np.int64)
+    v3 = (synth.splitmix64(43, idx) % np.uint64(9)).astype(np.float64) - 4.0
+    G3 = M.sr.sparse(n3, m3, (r3, c3, v3))
+    x3 = 1.0 + (np.arange(m3) % 7).astype(np.float64)
+    y3 = np.asarray(M.sr.smvm(G3, x3))
+    for mode in ("allgather", "halo"):
+        D3 = DistCsr.from_coo_chunks(M, hd, n3, m3, t(chunk(r3), dev), t(chunk(c3), dev), t(chunk(v3), dev),
+                                     force_mode=mode)
+        lo, hi = D3.bounds[rank], D3.bounds[rank + 1]
+        xlo, xhi = D3.plan.lo, D3.plan.hi
+        y = D3.smvm(t(x3[xlo:xhi], dev)).cpu().numpy()
+        assert np.array_equal(y, y3[lo:hi]), ("rectangular smvm", mode)
     dist.barrier()
     if rank == 0:
         print("DIST_GPU_OK", flush=True)

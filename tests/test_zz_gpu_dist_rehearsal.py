@@ -17,7 +17,7 @@ def _run(extra, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "512", "--backend", "gloo",
-           "--same-device", "--watchdog", "100"] + extra
+           "--same-device", "--watchdog", "100", "--c5-n", "20000", "--c5-triples", "400000"] + extra
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=170)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -29,6 +29,9 @@ def _run(extra, port):
 def test_two_ranks_halo():
     j = _run([], 29541)
     assert j["n_gpus"] == 2 and j["config"]["x_exchange"] == "halo"
+    # the strong-scaling leg (BASELINE configs[4] at rehearsal size): distributed assembly from per-rank slices
+    # of the counter-PRNG triple list, all-gather of x, parity gate inside bench.py
+    assert j["c5"]["n_gpus"] == 2 and j["c5"]["x_exchange"] == "allgather" and 390000 < j["c5"]["nnz_total"] <= 400000
     assert j["config"]["nnz_total"] == 5 * 512 * 1024 - 2 * 512 - 2 * 1024      # one 512 x 1024 grid
 
 
