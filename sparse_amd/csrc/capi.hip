@@ -8,6 +8,7 @@
 #include "assembly.hpp"
 #include "spmv.hpp"
 #include "spmv_pb.hpp"
+#include "spmv_2d.hpp"
 #include "spmm.hpp"
 #include "convert.hpp"
 #include "mono.hpp"
@@ -693,6 +694,11 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_pb_rows")) ctx->opt_spmv_pb_rows = value;
   else if (!strcmp(key, "spmv_pb_lines")) ctx->opt_spmv_pb_lines = value;
   else if (!strcmp(key, "spmv_pb_entries")) ctx->opt_spmv_pb_entries = value;
+  else if (!strcmp(key, "spmv_2d")) ctx->opt_spmv_2d = value;
+  else if (!strcmp(key, "spmv_2d_rows")) ctx->opt_spmv_2d_rows = value;
+  else if (!strcmp(key, "spmv_2d_cols")) ctx->opt_spmv_2d_cols = value;
+  else if (!strcmp(key, "spmv_2d_entries")) ctx->opt_spmv_2d_entries = value;
+  else if (!strcmp(key, "spmv_2d_dense")) ctx->opt_spmv_2d_dense = value;
   else if (!strcmp(key, "ablate")) ctx->opt_ablate = value;
   else if (!strcmp(key, "noalloc_scratch_bytes")) ctx->opt_noalloc_scratch_bytes = value;
   else return set_error(ctx, "unknown option '%s'", key);
@@ -708,6 +714,7 @@ int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *k
   if (!strcmp(key, "sort_algo")) return ctx->opt_sort_algo;
   if (!strcmp(key, "spmv_reorder")) return ctx->opt_spmv_reorder;
   if (!strcmp(key, "spmv_pb")) return ctx->opt_spmv_pb;
+  if (!strcmp(key, "spmv_2d")) return ctx->opt_spmv_2d;
   if (!strcmp(key, "num_cu")) return ctx->num_cu;
   if (!strcmp(key, "spmv_last_path")) return ctx->last_spmv_path;
   if (!strcmp(key, "spmv_last_col_bytes")) return ctx->last_spmv_col_bytes;

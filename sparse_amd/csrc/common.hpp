@@ -121,6 +121,8 @@ struct futhark_context {
   int64_t opt_spmv_pb = 0;  // two-pass SpMV (spmv_pb.hpp), 0 large skewed gather-bound records of 4-byte values, 1 also flat popularity, 2 always (tests), -1 never
   int64_t opt_spmv_pb_rows = 0, opt_spmv_pb_lines = 0, opt_spmv_pb_entries = 0;  // test overrides: rows per panel,
                                                                                  // 32-column lines per block, entries per panel
+  int64_t opt_spmv_2d = 0;  // 2-D blocked SpMV (spmv_2d.hpp): 0 large skewed records of 4-byte values, 2 always (tests), -1 never
+  int64_t opt_spmv_2d_rows = 0, opt_spmv_2d_cols = 0, opt_spmv_2d_entries = 0, opt_spmv_2d_dense = 0;  // test / lab overrides
   int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
   int64_t opt_noalloc_scratch_bytes = 0;  // tests: treat the static scratch array as this small (0 = its real size)
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
@@ -128,7 +130,7 @@ struct futhark_context {
   int64_t n_entries = 0;
   int64_t last_spmv_col_bytes = 0;  // bytes per column index the last SpMV kernel read (2, 4 or 8)
   int64_t opt_spmv_col16 = 0;  // 16-bit tile-relative columns: 0 decided per record, -1 never
-  int64_t last_spmv_path = 0;  // 0 one-pass, 1 hot-column renumbering, 2 column blocks, 3 two passes (tests read it back)
+  int64_t last_spmv_path = 0;  // 0 one-pass, 1 hot-column renumbering, 2 column blocks, 3 two passes, 4 2-D blocks (tests read it back)
 };
 
 namespace samd {
@@ -270,7 +272,12 @@ struct CsrBody {
   mutable uint32_t *pb_line_of_rank = nullptr;  // [nl] lines by descending entry count
   mutable uint16_t *pb_col16 = nullptr, *pb_row16 = nullptr;  // [nnz] column inside the block, row inside the panel
   mutable T *pb_val = nullptr, *pb_prod = nullptr;            // [nnz] values in piece order; products (rewritten per call)
+  mutable uint32_t *pb_dgroup = nullptr;                      // [padded entries / 32] pass 1's destination groups
   mutable T *pb_x = nullptr;                                  // [nb * w] x in block order (rewritten per call)
+  // 2-D blocked copy for power-law records (spmv_2d.hpp); built lazily
+  mutable int tb_state = 0;  // 0 undecided, 1 active, -1 rejected
+  mutable void *tb_ext = nullptr;
+  mutable void (*tb_ext_free)(futhark_context *, void *) = nullptr;
   // SpMM: tiles that go to the matrix cores (spmm.hpp), decided at the first product
   mutable int32_t *tile_split = nullptr;  // [ntiles] ids of the dense-block tiles, then of the others
   mutable int64_t n_mfma_tiles = -1;
@@ -306,6 +313,8 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->pb_val);
   dfree(ctx, b->pb_prod);
   dfree(ctx, b->pb_x);
+  dfree(ctx, b->pb_dgroup);
+  if (b->tb_ext_free) b->tb_ext_free(ctx, b->tb_ext);
   delete b;
 }
 

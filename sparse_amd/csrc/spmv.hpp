@@ -407,6 +407,11 @@ template <class T>
 int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted);
 template <class T>
 int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y);
+// 2-D blocked path (spmv_2d.hpp)
+template <class T>
+int tb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted);
+template <class T>
+int spmv_2d(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y);
 
 // Decides and, if worthwhile, builds the renumbering.  One-time host synchronisations (two small reads).
 template <class T>
@@ -467,6 +472,12 @@ int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
   if (!force && h2[0] * 2 < samples) { dfree(ctx, hot_perm); a->gather_flat = true; return 0; }  // flat popularity: nothing to pack
   // Large, wide, skewed: for 4-byte values the two-pass product with the x and y slices in LDS is faster than any
   // renumbering (C3: 1.65 against 2.08 ms) -- if the record qualifies it takes over and nothing more is built here.
+  // Large, wide, skewed: with 4-byte values the 2-D blocked product (x and y slices in LDS together, no product
+  // stream) comes first; what it declines goes to the two-pass product.
+  if (!force && a->tb_state == 0) {
+    if (tb_prepare<T>(ctx, a, true) != 0) { dfree(ctx, hot_perm); return 1; }
+    if (a->tb_state == 1) { dfree(ctx, hot_perm); return 0; }
+  }
   if (!force && a->pb_state == 0) {
     if (pb_prepare<T>(ctx, a, true) != 0) { dfree(ctx, hot_perm); return 1; }
     if (a->pb_state == 1) { dfree(ctx, hot_perm); return 0; }
@@ -891,9 +902,12 @@ int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
     return 0;
   }
   const int64_t algo = ctx->opt_spmv_algo;
+  if ((algo == 0 || algo == 1) && a->tb_state == 0 && ctx->opt_spmv_2d > 1) SAMD_TRY(tb_prepare<T>(ctx, a, false));
+  if ((algo == 0 || algo == 1) && a->tb_state == 1) { ctx->last_spmv_path = 4; return spmv_2d<T>(ctx, a, x, y); }
   if ((algo == 0 || algo == 1) && a->pb_state == 0 && ctx->opt_spmv_pb > 0) SAMD_TRY(pb_prepare<T>(ctx, a, false));
   if ((algo == 0 || algo == 1) && a->pb_state == 1) { ctx->last_spmv_path = 3; return spmv_pb<T>(ctx, a, x, y); }
-  if ((algo == 0 || algo == 1) && a->reorder_state == 0) SAMD_TRY(reorder_prepare<T>(ctx, a));  // may choose the two-pass path
+  if ((algo == 0 || algo == 1) && a->reorder_state == 0) SAMD_TRY(reorder_prepare<T>(ctx, a));  // may choose the 2-D or the two-pass path
+  if ((algo == 0 || algo == 1) && a->tb_state == 1) { ctx->last_spmv_path = 4; return spmv_2d<T>(ctx, a, x, y); }
   if ((algo == 0 || algo == 1) && a->pb_state == 1) { ctx->last_spmv_path = 3; return spmv_pb<T>(ctx, a, x, y); }
   ctx->last_spmv_path = 0;
   if ((algo == 0 || algo == 1) && a->reorder_state == 1) {

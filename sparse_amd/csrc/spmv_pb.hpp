@@ -56,6 +56,8 @@ constexpr int64_t kPbPanelEntries = 256 << 10;      // a panel is closed once it
 constexpr int kPbFoldMax = 16;                      // pass 2 folds a wavefront's runs when it holds at most this many (C3: 2: 0.95 ms, 8: 0.91, 16: 0.89, 32: 0.93, 48: 1.01)
 constexpr int64_t kPbMinBytes = 16 << 20;            // x at least this large (RMAT f32, bench/pb_scale_sweep.py, two-pass / one-pass ms:
                                                     // scale 20 0.21 / 0.15, 21 0.264 / 0.259, 22 0.47 / 0.51, 23 0.81 / 1.01, 24 1.62 / 2.08)
+constexpr int kPbFoldRows = 64;                     // a panel of fewer rows than this keeps its entries sorted by row: pass 2 folds runs
+constexpr int kPbFoldFlag = 0x8000;                 // row16 bit that says so
 constexpr int64_t kPbMinPiece = 128;               // auto mode: mean entries per piece below this -> not worth it
 
 // Popularity of the 32-column lines from every stride-th entry: the ranking only has to deal the lines to the
@@ -73,7 +75,9 @@ __global__ __launch_bounds__(kBlock) void pb_rank_kernel(const uint32_t *__restr
   if (q < nl) rank_of_line[line_of_rank[q]] = (uint32_t)q;
 }
 
-// key of entry e = block * np + panel (block-major: pass 1 streams a block's entries as one range)
+// key of entry e = (block * np + panel) * 32 + (row inside the panel) mod 32: block-major (pass 1 streams a block's
+// entries as one range), and inside a piece the entries come grouped by the LDS bank pair their row's accumulator
+// lives in (pb_build_kernel deals them out so that a group of 32 entries holds each bank pair about once)
 __global__ __launch_bounds__(kBlock) void pb_key_kernel(const int64_t *__restrict__ row_ptr,
                                                         const int32_t *__restrict__ col, int64_t nnz,
                                                         const int64_t *__restrict__ tile_lb, int64_t tile,
@@ -89,22 +93,38 @@ __global__ __launch_bounds__(kBlock) void pb_key_kernel(const int64_t *__restric
     if (panel_row[mid] <= r) lo = mid; else hi = mid;
   }
   const int64_t q = rank_of_line[col[e] / kPbLine];
-  keys[e] = (uint32_t)((q % nb) * np + lo);
+  keys[e] = (uint32_t)((((q % nb) * np + lo) << 5) | ((r - panel_row[lo]) & 31));
 }
 
-// piece_ptr[k] = first position whose key is >= k, k = 0 .. pieces
+// piece_ptr[k] = first position whose key (shifted right by `shift` bits) is >= k, k = 0 .. pieces
 __global__ __launch_bounds__(kBlock) void pb_piece_ptr_kernel(const uint32_t *__restrict__ sorted_keys, int64_t nnz,
-                                                              int64_t pieces, int64_t *__restrict__ piece_ptr) {
+                                                              int64_t pieces, int64_t *__restrict__ piece_ptr,
+                                                              int shift) {
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k > pieces) return;
   int64_t lo = 0, hi = nnz;
   while (lo < hi) {
     const int64_t mid = lo + (hi - lo) / 2;
-    if ((int64_t)sorted_keys[mid] < k) lo = mid + 1; else hi = mid;
+    if ((int64_t)(sorted_keys[mid] >> shift) < k) lo = mid + 1; else hi = mid;
   }
   piece_ptr[k] = lo;
 }
 
+// Padded piece sizes (multiples of 32 entries: every aligned group of 32 entries then belongs to one piece, in the
+// block-major layout pass 1 reads and in the panel-major layout it writes) in both orders, for the two scans.
+__global__ __launch_bounds__(kBlock) void pb_psz_kernel(const int64_t *__restrict__ piece_ptr, int64_t pieces, int64_t np,
+                                                        int64_t nb, int64_t *__restrict__ boff, int64_t *__restrict__ poff) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k > pieces) return;
+  if (k == pieces) { boff[k] = 0; poff[k] = 0; return; }
+  const int64_t sz = (piece_ptr[k + 1] - piece_ptr[k] + 31) & ~(int64_t)31;
+  const int64_t b = k / np, p = k - b * np;
+  boff[k] = sz;
+  poff[p * nb + b] = sz;
+}
+
+// Entry i of the sorted (block-major) list goes to its place in both padded layouts: column and value where pass 1
+// streams them (block-major), row where pass 2 streams it (panel-major).  Pads keep the fill: value 0, row 0xFFFF.
 template <class T>
 __global__ __launch_bounds__(kBlock) void pb_build_kernel(const int64_t *__restrict__ row_ptr,
                                                           const int32_t *__restrict__ col, const T *__restrict__ val,
@@ -113,18 +133,52 @@ __global__ __launch_bounds__(kBlock) void pb_build_kernel(const int64_t *__restr
                                                           const uint32_t *__restrict__ rank_of_line, int64_t nb,
                                                           int64_t np, const uint32_t *__restrict__ sorted_keys,
                                                           const uint32_t *__restrict__ perm,
+                                                          const int64_t *__restrict__ piece_ptr,
+                                                          const int64_t *__restrict__ boff, const int64_t *__restrict__ poff,
                                                           uint16_t *__restrict__ col16, uint16_t *__restrict__ row16,
                                                           T *__restrict__ pval) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nnz) return;
   const int64_t src = perm ? (int64_t)perm[i] : i;  // no sort pass ran (one piece): identity
-  const int64_t p = (int64_t)sorted_keys[i] % np;
+  const int64_t k = (int64_t)(sorted_keys[i] >> 5);
+  const int64_t b = k / np, p = k - b * np;
+  int64_t j = i - piece_ptr[k];
   const int64_t r = find_row(row_ptr, tile_lb, tile, src);
   const int32_t c = col[src];
   const int64_t q = rank_of_line[c / kPbLine];
-  col16[i] = (uint16_t)((q / nb) * kPbLine + (c % kPbLine));
-  row16[i] = (uint16_t)(r - panel_row[p]);
-  pval[i] = val[src];
+  // The sorted piece lists its entries by (row mod 32, row, column).  A panel of few rows (heavy rows) keeps that
+  // order -- equal rows adjacent -- and is flagged: pass 2 folds its runs inside the wavefront.  Every other piece
+  // is dealt out over its G groups of 32, entry j to group j mod G: neighbours in the sorted order (same bank pair)
+  // land in different groups, so one ds_add_f64 instruction sees each bank pair about once instead of ~4 times.
+  int flag = 0;
+  if (panel_row[p + 1] - panel_row[p] < kPbFoldRows) flag = kPbFoldFlag;
+  else {
+    const int64_t cnt = piece_ptr[k + 1] - piece_ptr[k], G = (cnt + 31) >> 5;
+    const int64_t sl = j / G;
+    j = (j % G) * 32 + ((sl & 1) * 16 + (sl >> 1));  // neighbours (possibly one bank pair twice) into different 16-lane halves
+  }
+  const int64_t db = boff[k] + j, dp = poff[p * nb + b] + j;
+  col16[db] = (uint16_t)((q / nb) * kPbLine + (c % kPbLine));
+  pval[db] = val[src];
+  row16[dp] = (uint16_t)((r - panel_row[p]) | flag);
+}
+
+__global__ __launch_bounds__(kBlock) void pb_bounds_kernel(const int64_t *__restrict__ boff, const int64_t *__restrict__ poff,
+                                                           int64_t np, int64_t nb, int64_t *__restrict__ bounds) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i <= nb) bounds[i] = boff[i * np];                       // boff has pieces + 1 = nb * np + 1 elements
+  else if (i <= nb + 1 + np) bounds[i] = poff[(i - nb - 1) * nb];
+}
+
+// dgroup[g] = the group of 32 entries in the panel-major layout that receives group g of the block-major one
+__global__ __launch_bounds__(kBlock) void pb_dgroup_kernel(const int64_t *__restrict__ boff, const int64_t *__restrict__ poff,
+                                                           int64_t pieces, int64_t np, int64_t nb,
+                                                           uint32_t *__restrict__ dgroup) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= pieces) return;
+  const int64_t b = k / np, p = k - b * np;
+  const int64_t g0 = boff[k] >> 5, g1 = boff[k + 1] >> 5, d0 = poff[p * nb + b] >> 5;
+  for (int64_t g = g0; g < g1; g++) dgroup[g] = (uint32_t)(d0 + (g - g0));
 }
 
 // x in block order: line of rank q -> block q mod nb, slot q / nb; w = columns per block
@@ -149,38 +203,44 @@ __device__ __forceinline__ int64_t pb_bcast64(int64_t v, int src) {
 }
 
 template <class T, int U>
-__global__ __launch_bounds__(kPbThreads) void pb_pass1_kernel(const int64_t *__restrict__ piece_ptr,
+__global__ __launch_bounds__(kPbThreads) void pb_pass1_kernel(const int64_t *__restrict__ block_ptr,
                                                               const uint16_t *__restrict__ col16,
                                                               const T *__restrict__ pval, const T *__restrict__ xperm,
-                                                              T *__restrict__ prod, int64_t np, int w, int lab) {
+                                                              const uint32_t *__restrict__ dgroup,
+                                                              T *__restrict__ prod, int w, int lab) {
   __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
   const int64_t b = blockIdx.x;
+  // (tried: the slice straight from x through line_of_rank, no renumbered copy -- the scattered 128-byte lines in
+  // front of the stream cost pass 1 0.11 ms where the separate copy kernel costs 0.06)
   {
     constexpr int PER = 16 / (int)sizeof(T);  // w is a multiple of 32 columns: whole 128-bit pieces
     const raw16 *src = reinterpret_cast<const raw16 *>(xperm + b * (int64_t)w);
     for (int j = threadIdx.x; j < w / PER; j += kPbThreads) reinterpret_cast<raw16 *>(xs)[j] = src[j];
   }
-  // the block's entries are one contiguous range; the gridDim.y workgroups of a block take equal shares of it
+  // the block's entries (all its pieces, each padded to a multiple of 32) are one contiguous range; the gridDim.y
+  // workgroups of a block take equal shares of it
   constexpr int64_t kStep = (int64_t)kPbThreads * U;
-  const int64_t s0 = piece_ptr[b * np], e0 = piece_ptr[(b + 1) * np];
+  const int64_t s0 = block_ptr[b], e0 = block_ptr[b + 1];
   const int64_t per = cdiv_dev(cdiv_dev(e0 - s0, kStep), (int64_t)gridDim.y) * kStep;
   const int64_t s = s0 + (int64_t)blockIdx.y * per;
   const int64_t e = s + per < e0 ? s + per : e0;
   __syncthreads();
   // Loads are never predicated: a load behind a branch makes the compiler wait for it at once (measured: the
-  // predicated form of this loop ran at 2 TB/s).  Partial steps clamp their addresses instead.  Steps start at
-  // a multiple of 32 entries so that every wavefront store covers whole 128-byte lines.
-  const int64_t abase = s & ~(int64_t)31;
-  for (int64_t i0 = abase; i0 < e; i0 += kStep) {
-    const bool full = i0 >= s && i0 + kStep <= e;  // uniform
+  // predicated form of this loop ran at 2 TB/s).  Partial steps clamp their addresses instead.  Every range
+  // starts at a multiple of 32 entries and a group of 32 entries has ONE destination group (dgroup), so every
+  // half-wavefront store covers one whole 128-byte line of the panel-major product stream.
+  for (int64_t i0 = s; i0 < e; i0 += kStep) {
+    const bool full = i0 + kStep <= e;  // uniform
     uint16_t c[U];
     T v[U];
+    uint32_t g[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t ii = i0 + (int64_t)u * kPbThreads + threadIdx.x;
-      const int64_t ic = full ? ii : (ii < s ? s : (ii < e ? ii : e - 1));
+      const int64_t ic = full ? ii : (ii < e ? ii : e - 1);
       c[u] = ntload(&col16[ic]);
       v[u] = ntload(&pval[ic]);
+      g[u] = dgroup[ic >> 5];
     }
     T pr[U];
 #pragma unroll
@@ -188,9 +248,10 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1_kernel(const int64_t *__r
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t ii = i0 + (int64_t)u * kPbThreads + threadIdx.x;
-      if (full || (ii >= s && ii < e)) {
-        if (lab == 3) prod[ii] = pr[u];                                                      // lab 3: plain store
-        else if (lab != 1 || pr[u] == (T)12345) __builtin_nontemporal_store(pr[u], &prod[ii]);  // lab 1: no store
+      if (full || ii < e) {
+        const int64_t d = ((int64_t)g[u] << 5) | (ii & 31);
+        if (lab == 3) prod[d] = pr[u];                                                      // lab 3: plain store
+        else if (lab != 1 || pr[u] == (T)12345) __builtin_nontemporal_store(pr[u], &prod[d]);  // lab 1: no store
       }
     }
   }
@@ -228,87 +289,89 @@ __device__ __forceinline__ void pb_seg_add(typename PbAcc<T>::type *ys, int row,
   }
 }
 
-// A wavefront walks pieces (panel p, block wave, wave + 16, ...) in chunks of 64 U entries.  The piece bounds are
-// fetched 64 pieces at a time (lane = piece) and the entries of chunk i + 1 are requested before chunk i is
-// added, across piece ends, so that no dependent pointer -> entry round trip sits in the loop.
-template <class T, int U>
-struct PbChunk {
-  int n;  // entries of this chunk (1 .. 64 U), the same in every lane
-  int r[U];
-  T v[U];
+// Workgroup = panel: its products (all blocks, panel-major layout) are ONE contiguous range, streamed by the 16
+// wavefronts in chunks of 64 U entries; chunk i + 1 is requested before chunk i is added.  Pads carry the row
+// number of a trash slot behind the slice, so nothing in the loop looks at them.
+// The loop is bound by the LDS atomics: a ds_add_f64 whose 64 lanes hold random rows runs ~109 cycles (27
+// conflict-free: 32 lanes into 32 bank pairs collide ~4 deep), 0.87 ms for C3's 3e8 entries.  So the entries of a
+// piece are stored dealt out by bank pair (pb_build_kernel): an instruction then sees each bank pair about once.
+// Panels of a few heavy rows are the exception: same-address atomics serialise whatever the banks, so those keep
+// their rows adjacent and fold the runs inside the wavefront first (flag bit in row16).
+template <class T> struct PbSlice {  // rows of y a panel holds; at most 2^14 so that the trash slot's number leaves bit 15 free
+  static constexpr int kFit = kPbSliceBytes / (int)sizeof(typename PbAcc<T>::type);
+  static constexpr int kRows = kFit < 16384 ? kFit : 16384;
 };
 
+template <class V>
+__device__ __forceinline__ V pb_wave_sum(V v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = (V)(v + wshfl_xor(v, d));
+  return v;
+}
+
 template <class T, int U>
-__global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__restrict__ piece_ptr,
+__global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__restrict__ panel_ptr,
                                                               const int64_t *__restrict__ panel_row,
                                                               const uint16_t *__restrict__ row16,
                                                               const T *__restrict__ prod, T *__restrict__ y,
-                                                              int64_t np, int64_t nb, int lab, int fold_max) {
+                                                              int lab, int fold_max) {
   typedef typename PbAcc<T>::type acc_t;
-  __shared__ acc_t ys[kPbSliceBytes / sizeof(acc_t)];
+  constexpr int kTrash = PbSlice<T>::kRows;
+  __shared__ acc_t ys[kTrash + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t p = blockIdx.x;
   const int64_t r0 = panel_row[p];
   const int rows = (int)(panel_row[p + 1] - r0);
   for (int j = tid; j < rows; j += kPbThreads) ys[j] = (acc_t)0;
   __syncthreads();
-  const int64_t npieces = wave < nb ? (nb - wave + kPbWaves - 1) / kPbWaves : 0;  // blocks wave, wave + 16, ...
-  int64_t ps = 0, pe = 0;  // bounds of piece (j & ~63) + lane of this wavefront's list
-  int64_t j = -1, cs = 0, ce = 0;
-  auto advance = [&]() -> bool {  // moves (cs, ce) to the next chunk; false when the pieces are used up
-    cs += 64 * U;
-    if (j >= 0 && cs < ce) return true;
-    for (j++; j < npieces; j++) {
-      if ((j & 63) == 0) {
-        const int64_t jj = j + lane;
-        ps = pe = 0;
-        if (jj < npieces) {
-          const int64_t k = (wave + jj * kPbWaves) * np + p;
-          ps = piece_ptr[k];
-          pe = piece_ptr[k + 1];
-        }
-      }
-      cs = pb_bcast64(ps, (int)(j & 63));
-      ce = pb_bcast64(pe, (int)(j & 63));
-      if (cs < ce) return true;
-    }
-    return false;
-  };
-  // Everything per lane is 32-bit and relative to the chunk (the chunk's base pointers are wavefront-uniform):
-  // with 64-bit indices per lane this kernel issued 63 vector instructions per 64 entries and was bound by them.
-  auto load = [&](PbChunk<T, U> &ch) {
+  const int64_t ps = panel_ptr[p], pe = panel_ptr[p + 1];
+  constexpr int64_t kChunk = 64 * U, kStride = (int64_t)kPbWaves * kChunk;
+  auto load = [&](int64_t cs, int (&r)[U], T (&v)[U]) {
     const uint16_t *rp = row16 + cs;
     const T *vp = prod + cs;
-    const int n = (int)(ce - cs < (int64_t)(64 * U) ? ce - cs : (int64_t)(64 * U));
-    ch.n = n;
+    if (cs + kChunk <= pe) {  // uniform
 #pragma unroll
-    for (int u = 0; u < U; u++) {  // never predicated (see pass 1): clamped offset, the row masked afterwards
-      const int o = lane + 64 * u;
-      const int oc = o < n ? o : n - 1;
-      ch.r[u] = (int)ntload(rp + oc);
-      ch.v[u] = ntload(vp + oc);
+      for (int u = 0; u < U; u++) {
+        r[u] = (int)ntload(rp + lane + 64 * u);
+        v[u] = ntload(vp + lane + 64 * u);
+      }
+    } else {  // the panel's last chunk: clamped offsets (never predicated loads), lanes beyond the end go to the trash slot
+      const int n = (int)(pe - cs);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int o = lane + 64 * u;
+        const int oc = o < n ? o : n - 1;
+        const int rr = (int)ntload(rp + oc);
+        r[u] = o < n ? rr : kTrash;
+        v[u] = ntload(vp + oc);
+      }
     }
   };
-  auto add = [&](const PbChunk<T, U> &ch) {
+  auto add = [&](const int (&r)[U], const T (&v)[U]) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (64 * u >= ch.n) break;  // uniform: the piece ended in an earlier instruction of the chunk
-      if (lab == 1) { if (ch.r[u] == 12345 && ch.v[u] == (T)77) ys[0] = (acc_t)ch.v[u]; }  // lab: stream only
-      else pb_seg_add<T>(ys, lane + 64 * u < ch.n ? ch.r[u] : -1, ch.v[u], lane, fold_max);  // lab 2: plain atomics
+      if (lab == 1) { if (r[u] == 12345 && v[u] == (T)77) ys[0] = (acc_t)v[u]; continue; }  // lab: stream only
+      if (fold_max > 0 && __ballot(r[u] & kPbFoldFlag) != 0ull)  // a panel of few, heavy rows: fold the runs first
+        pb_seg_add<T>(ys, r[u] & (kPbFoldFlag - 1), v[u], lane, fold_max < 64 ? 64 : fold_max);
+      else
+        atomicAdd(&ys[r[u] & (kPbFoldFlag - 1)], (acc_t)v[u]);
     }
   };
-  if (advance()) {
-    PbChunk<T, U> A, B;
-    load(A);
+  int64_t cs = ps + (int64_t)wave * kChunk;
+  if (cs < pe) {
+    int ra[U], rb[U];
+    T va[U], vb[U];
+    load(cs, ra, va);
     for (;;) {
-      const bool more_b = advance();
-      if (more_b) load(B);
-      add(A);
-      if (!more_b) break;
-      const bool more_a = advance();
-      if (more_a) load(A);
-      add(B);
-      if (!more_a) break;
+      const int64_t c1 = cs + kStride;
+      if (c1 < pe) load(c1, rb, vb);
+      add(ra, va);
+      if (c1 >= pe) break;
+      const int64_t c2 = c1 + kStride;
+      if (c2 < pe) load(c2, ra, va);
+      add(rb, vb);
+      if (c2 >= pe) break;
+      cs = c2;
     }
   }
   __syncthreads();
@@ -327,12 +390,12 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted) {
   const bool force = ctx->opt_spmv_pb > 1;
   // slice sizes (overridable for tests so that small records have many panels and blocks)
   const int64_t slice = kPbSliceBytes / (int64_t)sizeof(T);
-  const int64_t yslice = kPbSliceBytes / (int64_t)sizeof(typename PbAcc<T>::type);  // rows of y a panel can hold
+  const int64_t yslice = PbSlice<T>::kRows;  // rows of y a panel can hold
   int64_t R = ctx->opt_spmv_pb_rows > 0 ? ctx->opt_spmv_pb_rows : yslice;
   int64_t lpb = ctx->opt_spmv_pb_lines > 0 ? ctx->opt_spmv_pb_lines : slice / kPbLine;  // lines per block
   int64_t E = ctx->opt_spmv_pb_entries > 0 ? ctx->opt_spmv_pb_entries : kPbPanelEntries;
   if (R > yslice) R = yslice;
-  if (R > 65536) R = 65536;  // 16-bit row offsets
+  if (R > 65535) R = 65535;  // 16-bit row offsets
   if (lpb * kPbLine > slice) lpb = slice / kPbLine;
   if (lpb * kPbLine > 65536) lpb = 65536 / kPbLine;
   if (E < a->tile) E = a->tile;
@@ -376,11 +439,12 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted) {
   }
   const int64_t np = (int64_t)cuts.size() - 1;
   const int64_t pieces = np * nb;
-  if (pieces >= (1ll << 31) || a->nnz >= (int64_t)0xffff0000LL) return 0;
+  if (pieces >= (1ll << 26) || a->nnz >= (int64_t)0xffff0000LL) return 0;  // 32-bit keys: piece, then 5 bits of row
   if (!force && a->nnz / pieces < kPbMinPiece) return 0;
 
-  Tmp<int64_t> panel_row(ctx), piece_ptr(ctx);
-  Tmp<uint32_t> line_of_rank(ctx);
+  Tmp<int64_t> panel_row(ctx), piece_ptr(ctx), bounds(ctx);
+  Tmp<uint32_t> line_of_rank(ctx), dgroup(ctx);
+  int64_t ptotal = 0;  // entries of the padded layouts
   Tmp<uint16_t> col16(ctx), row16(ctx);
   Tmp<T> pval(ctx), prod(ctx), xperm(ctx);
   SAMD_TRY(panel_row.get(np + 1));
@@ -436,30 +500,61 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted) {
     uint32_t *eks = nullptr;
     const uint32_t *eperm = nullptr;
     SAMD_TRY((radix_sort_pairs<uint32_t, uint32_t>(ctx, ek_a.p, ek_b.p, (const uint32_t *)nullptr, ep_a.p, ep_b.p, a->nnz,
-                                                    0, bits_for(pieces), &eks, &eperm, sort_err)));
+                                                    0, bits_for(pieces) + 5, &eks, &eperm, sort_err)));
     hipLaunchKernelGGL(pb_piece_ptr_kernel, dim3((unsigned)cdiv(pieces + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
-                       (const uint32_t *)eks, a->nnz, pieces, piece_ptr.p);
+                       (const uint32_t *)eks, a->nnz, pieces, piece_ptr.p, 5);
     SAMD_LAUNCH_CHECK(ctx);
-    SAMD_TRY(col16.get(a->nnz));
-    SAMD_TRY(row16.get(a->nnz));
-    SAMD_TRY(pval.get(a->nnz));
+    // ---- both padded layouts: every piece rounded up to a multiple of 32 entries
+    Tmp<int64_t> boff(ctx), poff(ctx);
+    SAMD_TRY(boff.get(pieces + 1));
+    SAMD_TRY(poff.get(pieces + 1));
+    const unsigned pgrid = (unsigned)cdiv(pieces + 1, kBlock);
+    hipLaunchKernelGGL(pb_psz_kernel, dim3(pgrid), dim3(kBlock), 0, ctx->stream, (const int64_t *)piece_ptr.p, pieces, np, nb,
+                       boff.p, poff.p);
+    SAMD_LAUNCH_CHECK(ctx);
+    SAMD_TRY((device_scan<int64_t, OpAdd, PtrIn<int64_t>, true>(ctx, PtrIn<int64_t>{boff.p}, pieces + 1, (int64_t)0, OpAdd(),
+                                                                 boff.p, (int64_t *)nullptr)));
+    SAMD_TRY((device_scan<int64_t, OpAdd, PtrIn<int64_t>, true>(ctx, PtrIn<int64_t>{poff.p}, pieces + 1, (int64_t)0, OpAdd(),
+                                                                 poff.p, (int64_t *)nullptr)));
+    SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small, boff.p + pieces, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    int64_t flag[3];
+    SAMD_TRY(read_small(ctx, ctx->d_small, 3, flag));
+    if ((int)(flag[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
+    ptotal = flag[0];
+    if (ptotal >= (int64_t)0xffffffe0LL * 32) return 0;  // 32-bit group numbers
+    SAMD_TRY(col16.get(ptotal));
+    SAMD_TRY(row16.get(ptotal));
+    SAMD_TRY(pval.get(ptotal));
+    SAMD_TRY(dgroup.get(ptotal / 32));
+    SAMD_TRY(bounds.get(nb + 1 + np + 1));
+    SAMD_HIP(ctx, hipMemsetAsync(col16.p, 0, sizeof(uint16_t) * (size_t)ptotal, ctx->stream));
+    SAMD_HIP(ctx, hipMemsetAsync(pval.p, 0, sizeof(T) * (size_t)ptotal, ctx->stream));
+    SAMD_HIP(ctx, hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(row16.p), (unsigned short)PbSlice<T>::kRows,
+                                    (size_t)ptotal, ctx->stream));  // pads: the trash slot behind the slice
     hipLaunchKernelGGL((pb_build_kernel<T>), dim3(egrid), dim3(kBlock), 0, ctx->stream, (const int64_t *)a->row_ptr,
                        (const int32_t *)a->col32, (const T *)a->vals, a->nnz, (const int64_t *)a->tile_lb, a->tile,
                        (const int64_t *)panel_row.p, (const uint32_t *)rank_of_line.p, nb, np, (const uint32_t *)eks, eperm,
-                       col16.p, row16.p, pval.p);
+                       (const int64_t *)piece_ptr.p, (const int64_t *)boff.p, (const int64_t *)poff.p, col16.p, row16.p,
+                       pval.p);
     SAMD_LAUNCH_CHECK(ctx);
-    int64_t flag[3];
-    SAMD_TRY(read_small(ctx, ctx->d_small, 3, flag));  // also orders the temporaries' release after their use
-    if ((int)(flag[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
+    hipLaunchKernelGGL(pb_dgroup_kernel, dim3((unsigned)cdiv(pieces, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const int64_t *)boff.p, (const int64_t *)poff.p, pieces, np, nb, dgroup.p);
+    SAMD_LAUNCH_CHECK(ctx);
+    // block b's range in the block-major layout, then panel p's range in the panel-major one
+    hipLaunchKernelGGL(pb_bounds_kernel, dim3((unsigned)cdiv(nb + 1 + np + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const int64_t *)boff.p, (const int64_t *)poff.p, np, nb, bounds.p);
+    SAMD_LAUNCH_CHECK(ctx);
+    SAMD_TRY(read_small(ctx, ctx->d_small, 1, flag));  // orders the temporaries' release after their use
   }
-  SAMD_TRY(prod.get(a->nnz));
+  SAMD_TRY(prod.get(ptotal));
   SAMD_TRY(xperm.get(nb * w));
   a->pb_np = np;
   a->pb_nb = nb;
   a->pb_w = w;
   a->pb_nl = nl;
   a->pb_panel_row = panel_row.release();
-  a->pb_piece_ptr = piece_ptr.release();
+  a->pb_piece_ptr = bounds.release();  // [nb + 1] block ranges (block-major layout), then [np + 1] panel ranges (panel-major)
+  a->pb_dgroup = dgroup.release();
   a->pb_line_of_rank = line_of_rank.release();
   a->pb_col16 = col16.release();
   a->pb_row16 = row16.release();
@@ -483,11 +578,12 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
   if (split > 65535) split = 65535;
   hipLaunchKernelGGL((pb_pass1_kernel<T, 8>), dim3((unsigned)a->pb_nb, (unsigned)split), dim3(kPbThreads), 0, ctx->stream,
                      (const int64_t *)a->pb_piece_ptr, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,
-                     (const T *)a->pb_x, a->pb_prod, a->pb_np, (int)a->pb_w, (int)((ctx->opt_ablate >> 2) & 3));
+                     (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w,
+                     (int)((ctx->opt_ablate >> 2) & 3));
   SAMD_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL((pb_pass2_kernel<T, 8>), dim3((unsigned)a->pb_np), dim3(kPbThreads), 0, ctx->stream,
-                     (const int64_t *)a->pb_piece_ptr, (const int64_t *)a->pb_panel_row, (const uint16_t *)a->pb_row16,
-                     (const T *)a->pb_prod, y, a->pb_np, a->pb_nb, (int)(ctx->opt_ablate & 3),
+                     (const int64_t *)(a->pb_piece_ptr + a->pb_nb + 1), (const int64_t *)a->pb_panel_row,
+                     (const uint16_t *)a->pb_row16, (const T *)a->pb_prod, y, (int)(ctx->opt_ablate & 3),
                      (ctx->opt_ablate & 3) == 2 ? 0 : (ctx->opt_ablate >> 4) ? (int)(ctx->opt_ablate >> 4) : kPbFoldMax);
   SAMD_LAUNCH_CHECK(ctx);
   return 0;

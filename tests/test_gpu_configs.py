@@ -92,8 +92,11 @@ def test_c3_rmat_scale_24_f32(env):
     x = torch.rand(n, device=dev, dtype=torch.float32) + 0.5
     y = torch.as_tensor(M.sr.smvm(A, x), device=dev).clone()
     assert ctx.get_option("spmv_last_path") == 3, "the two-pass path was not chosen"
-    assert torch.equal(torch.as_tensor(M.sr.smvm(A, x), device=dev), y)         # reproducible
-    del A
+    # again: the order in which the LDS atomics of pass 2 land is not fixed, so the last bit of an f32 sum may
+    # differ between two runs (the f64 accumulator absorbs the rest)
+    y_again = torch.as_tensor(M.sr.smvm(A, x), device=dev)
+    assert float(((y_again - y).abs() / y.abs().clamp_min(1e-30)).max()) <= 2e-7
+    del A, y_again
     ctx.clear_caches()
     ctx.set_option("spmv_pb", -1)
     ctx.set_option("spmv_reorder", -1)

@@ -338,6 +338,48 @@ def test_smvm_two_pass_panels(ctx, dtype, geom):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+@pytest.mark.parametrize("geom", [(0, 0, 0, 0), (64, 64, 512, 8), (700, 160, 4096, 40), (300, 32, 100000, 1)],
+                         ids=["one_panel", "tiny", "mid", "all_dense"])
+def test_smvm_2d_blocks(ctx, dtype, geom):
+    """spmv_2d=2 forces the 2-D blocked product (normally kept for large, wide, skewed records of 4-byte values):
+    columns renumbered by popularity, entries regrouped into (row panel) x (column block) pieces; the x slice
+    of a well-filled piece and the panel's y slice sit in LDS together, thinly filled pieces gather from global
+    memory; a heavy panel is cut into units whose sums meet in a small buffer.  The overrides (rows per panel,
+    columns per block, entries per unit, entries that make a piece dense) shrink the geometry so that small
+    records have many panels, blocks, units and both kinds of piece.  Against the oracle within the dtype's bar
+    (another summation order), i32 exact; a second x on the cached copy; a dense row, empty rows, one column,
+    one row, column numbers beyond the first blocks; the record itself untouched."""
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    rows, cols, entries, dense = geom
+    ctx.set_option("spmv_2d", 2)
+    ctx.set_option("spmv_2d_rows", rows)
+    ctx.set_option("spmv_2d_cols", cols)
+    ctx.set_option("spmv_2d_entries", entries)
+    ctx.set_option("spmv_2d_dense", dense)
+    try:
+        for n, m, gen in ((3000, 9000, lambda: skewed_coo(3000, 9000, dtype, 8)),
+                          (20000, 5000, lambda: random_coo(20000, 5000, 90000, dtype, seed=91, dup_frac=0.05)),
+                          (1, 7000, lambda: random_coo(1, 7000, 6000, dtype, seed=93)),
+                          (6000, 1, lambda: random_coo(6000, 1, 900, dtype, seed=94)),
+                          (700, 6000, lambda: tuple(a if i != 1 else a + 1500 for i, a in
+                                                    enumerate(random_coo(700, 4500, 20000, dtype, seed=92))))):
+            r, c, v = gen()
+            A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
+            x = synth.uniform_values(5, m, dtype)
+            y = ctx.array(np.full(n, 7, NP[dtype]), dtype)       # every row must be written, also the empty ones
+            M.sr.smvm_into(y, A, x)
+            assert ctx.get_option("spmv_last_path") == 4
+            close(y.numpy(), O.sr_smvm(Ao, x), dtype)
+            x2 = synth.uniform_values(6, m, dtype)
+            close(M.sr.smvm(A, x2), O.sr_smvm(Ao, x2), dtype)
+            close(M.sr.smvm(A, x), O.sr_smvm(Ao, x), dtype)       # the buffer of the cut panels was left clean
+            assert_same_record(A, Ao)
+    finally:
+        for k in ("spmv_2d", "spmv_2d_rows", "spmv_2d_cols", "spmv_2d_entries", "spmv_2d_dense"):
+            ctx.set_option(k, 0)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
 def test_smvm_16_bit_columns_and_row_offsets_on_a_large_banded_record(ctx, dtype):
     """Records of more than 4096 tiles read 16-bit tile-relative row offsets, and 16-bit tile-relative columns
     when every tile spans fewer than 65536 columns (banded / stencil).  Against the oracle; bit-identical to the
