@@ -125,7 +125,7 @@ def c5_leg(args, torch, dist, world, rank, dev, ctx, M):
     xg = 1.0 + (torch.arange(n, device=dev) % 7).double()
     want = torch.zeros(n, dtype=torch.float64, device=dev)
     chunk = 1 << 28
-    for s in range(0, r.numel(), chunk):
+    for s in range(0, r.numel(), chunk):        # sums of small integers: exact in any order
         want.index_add_(0, r[s:s + chunk], v[s:s + chunk] * xg[c[s:s + chunk]])
     if dist is not None:
         dist.all_reduce(want)

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void reorder_gather_x_kernel(const T *__res
 
 // two-pass path for gather-bound power-law records (spmv_pb.hpp)
 template <class T>
-int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted);
+int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat = false);
 template <class T>
 int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y);
 // 2-D blocked path (spmv_2d.hpp)
@@ -469,7 +469,12 @@ int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
   int64_t h2[3];
   if (read_small(ctx, ctx->d_small, 3, h2) != 0) { dfree(ctx, hot_perm); return 1; }
   if ((int)(h2[2] & 0xffffffff) != 0) { dfree(ctx, hot_perm); return set_error(ctx, "internal: radix sort look-back timed out"); }
-  if (!force && h2[0] * 2 < samples) { dfree(ctx, hot_perm); a->gather_flat = true; return 0; }  // flat popularity: nothing to pack
+  if (!force && h2[0] * 2 < samples) {  // flat popularity: nothing to pack -- the two-pass product, else column blocks
+    dfree(ctx, hot_perm);
+    a->gather_flat = true;
+    if (a->pb_state == 0) SAMD_TRY(pb_prepare<T>(ctx, a, true, true));
+    return 0;
+  }
   // Large, wide, skewed: for 4-byte values the two-pass product with the x and y slices in LDS is faster than any
   // renumbering (C3: 1.65 against 2.08 ms) -- if the record qualifies it takes over and nothing more is built here.
   // Large, wide, skewed: with 4-byte values the 2-D blocked product (x and y slices in LDS together, no product

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__r
 // span a wide column range and that column popularity is skewed (the default route, option 0).  Option 1 also
 // admits records of flat popularity (own checks below), 2 admits anything (tests), -1 nothing.
 template <class T>
-int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted) {
+int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat) {
   a->pb_state = -1;
   if (ctx->opt_spmv_pb < 0 || (ctx->opt_spmv_pb == 0 && !vetted)) return 0;
   if (!a->col32 || a->nnz == 0 || a->n == 0 || a->tile <= 0) return 0;
@@ -405,7 +405,11 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted) {
   if (!force) {
     // the gather has to be the problem: 4-byte values (16 B moved per entry against 8; for 8-byte values the
     // one-pass paths are on par), x beyond the L2s, most tiles spanning a wide column range
-    if (sizeof(T) != 4 || a->m * (int64_t)sizeof(T) < kPbMinBytes) return 0;
+    // skewed popularity: 4-byte values only (16 B moved per entry against 8; with 8-byte values the hot-column
+    // renumbering is on par).  Flat popularity (uniform random: no renumbering can help, every gather of the
+    // one-pass kernels misses L2): any value size -- measured f64, m = 1e7: 100 entries per row 0.78 ms against
+    // 1.04 with column blocks, 12.5 per row 0.89 against 2.42, the 1e9-entry record 5.7 against 6.3.
+    if ((sizeof(T) != 4 && !flat) || a->m * (int64_t)sizeof(T) < kPbMinBytes) return 0;
     const int64_t np_est = cdiv(a->n, R) + cdiv(a->nnz, E);
     if (a->nnz / (np_est * nb) < kPbMinPiece) return 0;
   }

@@ -369,7 +369,7 @@ class DistCsr:
         else:
             per = -(-m_glob // world)
             bounds = [min(k * per, m_glob) for k in range(world)] + [m_glob]
-        needed = torch.unique(cs)
+        needed = torch.unique(cs) if world > 1 else cs[:0]      # a single rank exchanges nothing: skip the sort
         plan = ExchangePlan(dist, bounds, needed, dev, force_mode)
         del needed
         n_loc = row_hi - row_lo

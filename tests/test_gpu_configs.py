@@ -8,8 +8,8 @@ through the C ABI.
                   index arrays against torch's coalesce (independent of this library), the two-pass product
                   against the one-pass kernel within 1e-5, the i32 twin exactly
   configs[4]  C5  uniform random 1e7 x 1e7, 1e9 triples, f64, the whole record on one GPU (the 8-rank run is
-                  the driver's; the 1/8 shard is in test_gpu_fullsize.py): column blocks against torch's own
-                  index_add_ on the same triples within 1e-12, reproducible bit for bit
+                  the driver's; the 1/8 shard is in test_gpu_fullsize.py): the two-pass product against torch's own
+                  index_add_ on the same triples within 1e-12
 """
 import numpy as np
 import pytest
@@ -141,8 +141,10 @@ def test_c5_random_1e9_f64_whole_record_on_one_gpu(env):
     ctx.clear_caches()
     x = torch.rand(m, device=dev, dtype=torch.float64) + 0.5
     y = torch.as_tensor(M.sr.smvm(A, x), device=dev).clone()
-    assert ctx.get_option("spmv_last_path") == 2, "column blocks were not chosen"
-    assert torch.equal(torch.as_tensor(M.sr.smvm(A, x), device=dev), y)         # reproducible bit for bit
+    assert ctx.get_option("spmv_last_path") == 3, "the two-pass path was not chosen"
+    y_again = torch.as_tensor(M.sr.smvm(A, x), device=dev)      # reproducible up to the order of the LDS atomics
+    assert float(((y_again - y).abs() / y.abs()).max()) <= 1e-15
+    del y_again
     # row_off against torch's histogram of the same row ids (duplicates counted once: compare the totals
     # and monotonicity, then the exact histogram on the rows of the merged record)
     ro = torch.as_tensor(A.fields()[0], device=dev)

@@ -132,11 +132,12 @@ def test_c4_smm_matrix_cores_against_the_entry_path_and_linearity():
     assert torch.equal(C2, 2.0 * C)          # scaling by a power of two is exact in every partial sum
 
 
-def test_c5_row_shard_column_blocks_against_the_plain_kernel():
+def test_c5_row_shard_two_pass_and_column_blocks_against_the_plain_kernel():
     """configs[4], what one of 8 ranks holds: uniform random 1.25e6 x 1e7, 1.25e8 triples, f64.  Auto mode
-    picks the column-blocked product for it; the same record with spmv_cblk -1 runs the plain streaming
-    kernel.  Different kernels and summation orders: within 1e-12 relative; the column-blocked one is
-    reproducible bit for bit."""
+    picks the two-pass product for a wide record of flat column popularity; with spmv_pb -1 it falls back to the
+    column-blocked product, with spmv_cblk -1 as well to the plain streaming kernel.  Three kernels, three
+    summation orders: within 1e-12 relative of each other and of torch's own scatter-add; the column-blocked
+    one is reproducible bit for bit, the two-pass one up to the order its LDS atomics land in."""
     torch, ctx = _ctx()
     from sparse_amd import mk_compressed, synth
     M = mk_compressed("f64", ctx)
@@ -145,15 +146,26 @@ def test_c5_row_shard_column_blocks_against_the_plain_kernel():
     x = torch.rand(m, device="cuda:0", dtype=torch.float64) + 0.5
     A = M.sr.sparse(n, m, (r, c, v))
     y = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0").clone()
+    assert ctx.get_option("spmv_last_path") == 3, "the two-pass path was not chosen"
     y_again = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0")
-    assert torch.equal(y, y_again)
-    ctx.set_option("spmv_cblk", -1)
+    assert float(((y - y_again).abs() / y.abs()).max()) <= 1e-15
+    del A
+    ctx.set_option("spmv_pb", -1)
     try:
-        A2 = M.sr.sparse(n, m, (r, c, v))       # a fresh record: the choice is made at a record's first product
+        A1 = M.sr.sparse(n, m, (r, c, v))       # a fresh record: the choice is made at a record's first product
+        y1 = torch.as_tensor(M.sr.smvm(A1, x), device="cuda:0").clone()
+        assert ctx.get_option("spmv_last_path") == 2, "column blocks were not chosen"
+        assert torch.equal(torch.as_tensor(M.sr.smvm(A1, x), device="cuda:0"), y1)
+        del A1
+        ctx.set_option("spmv_cblk", -1)
+        A2 = M.sr.sparse(n, m, (r, c, v))
         y2 = torch.as_tensor(M.sr.smvm(A2, x), device="cuda:0")
+        assert ctx.get_option("spmv_last_path") == 0
     finally:
         ctx.set_option("spmv_cblk", 0)
+        ctx.set_option("spmv_pb", 0)
     assert float(((y - y2).abs() / y2.abs()).max()) <= 1e-12
+    assert float(((y1 - y2).abs() / y2.abs()).max()) <= 1e-12
     # and against torch's own COO path on the same triples (independent of this library)
     want = torch.zeros(n, device="cuda:0", dtype=torch.float64).index_add_(0, r, v * x[c])
     assert float(((y - want).abs() / want.abs()).max()) <= 1e-12
