@@ -568,6 +568,8 @@ int m_fields(futhark_context *ctx, futhark_i64_1d **ci, VA **va, const H *a) {
 
 }  // namespace
 
+#include "group.hpp"
+
 extern "C" {
 
 // ------------------------------------------------------------------ context
@@ -1404,5 +1406,251 @@ int sparse_amd_mtx_write(const char *path, int64_t n, int64_t m, int64_t count, 
 }
 
 void sparse_amd_mtx_free(void *p) { free(p); }
+
+// --------------------------------------------- one process, several devices (group.hpp)
+int sparse_amd_group_new(struct sparse_amd_group **out, int ndev, const int *devices, const char *transport) {
+  *out = nullptr;
+  if (ndev < 1 || ndev > 64) return 1;
+  sparse_amd_group *g = new sparse_amd_group();
+  *out = g;  // always returned: the error text lives in it
+  g->G = ndev;
+  bool distinct = true;
+  for (int k = 0; k < ndev; k++) {
+    g->dev.push_back(devices ? devices[k] : k);
+    for (int j = 0; j < k; j++) distinct = distinct && g->dev[(size_t)j] != g->dev[(size_t)k];
+  }
+  const bool want_rccl = transport && !strcmp(transport, "rccl");
+  const bool want_peer = transport && !strcmp(transport, "peer");
+  if (transport && !want_rccl && !want_peer) return group_error(g, "group: unknown transport '%s' (rccl, peer)", transport);
+  if (want_rccl && !distinct) return group_error(g, "group: RCCL needs distinct devices (the peer transport rehearses several members on one)");
+  for (int k = 0; k < ndev; k++) {
+    futhark_context_config *cfg = futhark_context_config_new();
+    cfg->device = g->dev[(size_t)k];
+    futhark_context *c = futhark_context_new(cfg);
+    futhark_context_config_free(cfg);
+    g->ctx.push_back(c);
+    if (c->has_err) return group_member_error(g, k, "context");
+  }
+  g->ev_x.assign((size_t)ndev, nullptr);
+  g->ev_done.assign((size_t)ndev, nullptr);
+  for (int k = 0; k < ndev; k++) {
+    SAMD_GHIP(g, hipSetDevice(g->dev[(size_t)k]));
+    SAMD_GHIP(g, hipEventCreateWithFlags(&g->ev_x[(size_t)k], hipEventDisableTiming));
+    SAMD_GHIP(g, hipEventCreateWithFlags(&g->ev_done[(size_t)k], hipEventDisableTiming));
+    for (int j = 0; j < ndev; j++) {  // direct peer access where the devices differ (ignored if already on / unsupported)
+      if (g->dev[(size_t)j] == g->dev[(size_t)k]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, g->dev[(size_t)k], g->dev[(size_t)j]) == hipSuccess && can)
+        (void)hipDeviceEnablePeerAccess(g->dev[(size_t)j], 0);
+      (void)hipGetLastError();
+    }
+  }
+  if (ndev > 1 && distinct && !want_peer) {
+    std::string why;
+    if (!g->rccl.load(&why)) {
+      if (want_rccl) return group_error(g, "group: %s", why.c_str());
+    } else {
+      g->comm.assign((size_t)ndev, nullptr);
+      SAMD_GNCCL(g, g->rccl.CommInitAll(g->comm.data(), ndev, g->dev.data()));
+      g->use_rccl = true;
+    }
+  }
+  return 0;
+}
+
+void sparse_amd_group_free(struct sparse_amd_group *g) { group_destroy(g); }
+
+char *sparse_amd_group_get_error(struct sparse_amd_group *g) {
+  if (!g || !g->has_err) return nullptr;
+  g->has_err = false;
+  return strdup(g->err.c_str());
+}
+
+int sparse_amd_group_size(struct sparse_amd_group *g) { return g->G; }
+const char *sparse_amd_group_transport(struct sparse_amd_group *g) { return g->G == 1 ? "none" : (g->use_rccl ? "rccl" : "peer"); }
+struct futhark_context *sparse_amd_group_context(struct sparse_amd_group *g, int k) {
+  return (k >= 0 && k < g->G) ? g->ctx[(size_t)k] : nullptr;
+}
+
+int sparse_amd_group_sync(struct sparse_amd_group *g) {
+  for (int k = 0; k < g->G; k++)
+    if (futhark_context_sync(g->ctx[(size_t)k]) != 0) return group_member_error(g, k, "sync");
+  return 0;
+}
+
+int sparse_amd_dcsr_f64_free(struct sparse_amd_group *g, struct sparse_amd_dcsr_f64 *A) {
+  if (!A) return 0;
+  for (int k = 0; k < (int)A->A.size(); k++) {
+    futhark_context *c = g->ctx[(size_t)k];
+    if (A->A[(size_t)k]) futhark_free_opaque_csr_f64(c, A->A[(size_t)k]);
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(g->dev[(size_t)k]);
+    if (k < (int)A->x_full.size()) dfree(c, A->x_full[(size_t)k]);
+  }
+  delete A;
+  return 0;
+}
+
+// sr.sparse n m coo (compressed.fut:154-160) with the rows dealt to the members: host triples in, one csr handle per
+// member out.  Splitters: nearly equal triple counts, cut at the bins of a coarse row histogram.
+int sparse_amd_dcsr_f64_sparse(struct sparse_amd_group *g, struct sparse_amd_dcsr_f64 **out, int64_t n, int64_t m,
+                               const int64_t *rs, const int64_t *cs, const double *vs, int64_t count) {
+  *out = nullptr;
+  if (n < 0 || m < 0 || count < 0) return group_error(g, "sparse: negative size");
+  const int G = g->G;
+  const int shift = bits_for(n) > 16 ? bits_for(n) - 16 : 0;
+  const int64_t nbins = n > 0 ? ((n - 1) >> shift) + 1 : 1;
+  std::vector<int64_t> hist((size_t)nbins, 0);
+  for (int64_t i = 0; i < count; i++) {
+    if (rs[i] < 0 || rs[i] >= n || cs[i] < 0 || cs[i] >= m)
+      return group_error(g, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
+    hist[(size_t)(rs[i] >> shift)]++;
+  }
+  sparse_amd_dcsr_f64 *A = new sparse_amd_dcsr_f64();
+  A->n = n; A->m = m;
+  A->rb.assign((size_t)G + 1, n);
+  A->rb[0] = 0;
+  {
+    int64_t cum = 0;
+    int next = 1;
+    for (int64_t b = 0; b < nbins && next < G; b++) {
+      cum += hist[(size_t)b];
+      while (next < G && cum >= count * next / G) {  // bins [0, b] hold at least member next's share
+        const int64_t cut = (b + 1) << shift;
+        A->rb[(size_t)next++] = cut < n ? cut : n;
+      }
+    }
+  }
+  if (n == m) A->cb = A->rb;
+  else {
+    const int64_t per = cdiv(m, G);
+    A->cb.assign((size_t)G + 1, m);
+    for (int k = 0; k < G; k++) A->cb[(size_t)k] = k * per < m ? k * per : m;
+  }
+  // triples to their owners, input order kept (duplicates are then summed as on one device)
+  std::vector<int64_t> cnt((size_t)G, 0);
+  std::vector<int> owner((size_t)count);
+  for (int64_t i = 0; i < count; i++) {
+    int k = 0;
+    while (rs[i] >= A->rb[(size_t)k + 1]) k++;
+    owner[(size_t)i] = k;
+    cnt[(size_t)k]++;
+  }
+  A->A.assign((size_t)G, nullptr);
+  A->x_full.assign((size_t)G, nullptr);
+  int rc = 0;
+  for (int k = 0; k < G && rc == 0; k++) {
+    std::vector<int64_t> r((size_t)cnt[(size_t)k]), c((size_t)cnt[(size_t)k]);
+    std::vector<double> v((size_t)cnt[(size_t)k]);
+    int64_t q = 0;
+    for (int64_t i = 0; i < count; i++)
+      if (owner[(size_t)i] == k) { r[(size_t)q] = rs[i] - A->rb[(size_t)k]; c[(size_t)q] = cs[i]; v[(size_t)q] = vs[i]; q++; }
+    futhark_context *cx = g->ctx[(size_t)k];
+    futhark_i64_1d *ar = futhark_new_i64_1d(cx, r.data(), q), *ac = futhark_new_i64_1d(cx, c.data(), q);
+    futhark_f64_1d *av = futhark_new_f64_1d(cx, v.data(), q);
+    if (!ar || !ac || !av ||
+        futhark_entry_csr_f64_sparse(cx, &A->A[(size_t)k], A->rb[(size_t)k + 1] - A->rb[(size_t)k], m, ar, ac, av) != 0)
+      rc = group_member_error(g, k, "sparse");
+    if (ar) futhark_free_i64_1d(cx, ar);
+    if (ac) futhark_free_i64_1d(cx, ac);
+    if (av) futhark_free_f64_1d(cx, av);
+    if (rc == 0) {
+      std::lock_guard<std::mutex> lk(cx->mu);
+      (void)hipSetDevice(g->dev[(size_t)k]);
+      if (dalloc(cx, &A->x_full[(size_t)k], m) != 0) rc = 2;
+    }
+    if (rc == 2) rc = group_member_error(g, k, "sparse (x buffer)");
+  }
+  if (rc != 0) { sparse_amd_dcsr_f64_free(g, A); return rc; }
+  *out = A;
+  return 0;
+}
+
+int sparse_amd_dcsr_f64_bounds(struct sparse_amd_group *g, const struct sparse_amd_dcsr_f64 *A, int64_t *row_bounds,
+                               int64_t *col_bounds) {
+  for (int k = 0; k <= g->G; k++) {
+    if (row_bounds) row_bounds[k] = A->rb[(size_t)k];
+    if (col_bounds) col_bounds[k] = A->cb[(size_t)k];
+  }
+  return 0;
+}
+
+struct futhark_opaque_csr_f64 *sparse_amd_dcsr_f64_member(struct sparse_amd_group *g, const struct sparse_amd_dcsr_f64 *A, int k) {
+  return (k >= 0 && k < g->G) ? A->A[(size_t)k] : nullptr;
+}
+
+int sparse_amd_dvec_f64_free(struct sparse_amd_group *g, struct sparse_amd_dvec_f64 *v) {
+  if (!v) return 0;
+  for (int k = 0; k < (int)v->d.size(); k++) {
+    futhark_context *c = g->ctx[(size_t)k];
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(g->dev[(size_t)k]);
+    dfree(c, v->d[(size_t)k]);
+  }
+  delete v;
+  return 0;
+}
+
+// A vector cut like A's columns (like_rows == 0: an operand of smvm) or like its rows (a result); host == NULL
+// leaves it uninitialised.
+int sparse_amd_dvec_f64_new(struct sparse_amd_group *g, struct sparse_amd_dvec_f64 **out, const struct sparse_amd_dcsr_f64 *A,
+                            int like_rows, const double *host) {
+  *out = nullptr;
+  sparse_amd_dvec_f64 *v = new sparse_amd_dvec_f64();
+  v->b = like_rows ? A->rb : A->cb;
+  v->d.assign((size_t)g->G, nullptr);
+  int bad = -1;
+  hipError_t he = hipSuccess;
+  for (int k = 0; k < g->G && bad < 0; k++) {
+    futhark_context *c = g->ctx[(size_t)k];
+    std::lock_guard<std::mutex> lk(c->mu);
+    (void)hipSetDevice(g->dev[(size_t)k]);
+    const int64_t cnt = v->b[(size_t)k + 1] - v->b[(size_t)k];
+    if (dalloc(c, &v->d[(size_t)k], cnt) != 0) { bad = k; break; }
+    if (host && cnt > 0) {
+      he = hipMemcpyAsync(v->d[(size_t)k], host + v->b[(size_t)k], sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, c->stream);
+      if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+      if (he != hipSuccess) { (void)hipGetLastError(); bad = k; }
+    }
+  }
+  if (bad >= 0) {
+    if (he != hipSuccess) group_error(g, "dvec: copy to member %d failed: %s", bad, hipGetErrorString(he));
+    else group_member_error(g, bad, "dvec");
+    sparse_amd_dvec_f64_free(g, v);
+    return 1;
+  }
+  *out = v;
+  return 0;
+}
+
+int sparse_amd_dvec_f64_values(struct sparse_amd_group *g, const struct sparse_amd_dvec_f64 *v, double *host) {
+  for (int k = 0; k < g->G; k++) {
+    futhark_context *c = g->ctx[(size_t)k];
+    std::lock_guard<std::mutex> lk(c->mu);
+    SAMD_GHIP(g, hipSetDevice(g->dev[(size_t)k]));
+    const int64_t cnt = v->b[(size_t)k + 1] - v->b[(size_t)k];
+    if (cnt > 0)
+      SAMD_GHIP(g, hipMemcpyAsync(host + v->b[(size_t)k], v->d[(size_t)k], sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost,
+                                  c->stream));
+  }
+  for (int k = 0; k < g->G; k++) {
+    SAMD_GHIP(g, hipSetDevice(g->dev[(size_t)k]));
+    SAMD_GHIP(g, hipStreamSynchronize(g->ctx[(size_t)k]->stream));
+  }
+  return 0;
+}
+
+void *sparse_amd_dvec_f64_member_ptr(struct sparse_amd_group *g, const struct sparse_amd_dvec_f64 *v, int k, int64_t *len) {
+  if (k < 0 || k >= g->G) return nullptr;
+  if (len) *len = v->b[(size_t)k + 1] - v->b[(size_t)k];
+  return v->d[(size_t)k];
+}
+
+// sr.smvm (compressed.fut:134-146) over the members: every member's slice of x reaches every member, then every
+// member multiplies its rows.  Asynchronous; sparse_amd_group_sync or sparse_amd_dvec_f64_values wait.
+int sparse_amd_dcsr_f64_smvm(struct sparse_amd_group *g, struct sparse_amd_dvec_f64 *y, const struct sparse_amd_dcsr_f64 *A,
+                             const struct sparse_amd_dvec_f64 *x) {
+  return group_smvm(g, y, A, x);
+}
 
 }  // extern "C"
