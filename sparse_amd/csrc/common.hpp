@@ -247,6 +247,8 @@ struct CsrBody {
   mutable int col16_state = 0;  // 0 undecided, 1 active, -1 rejected
   mutable uint16_t *col16 = nullptr;   // [nnz]
   mutable int32_t *tile_c0 = nullptr;  // [ntiles]
+  mutable int32_t *fix_list = nullptr;  // [4 ntiles] rows the fix-up launch folds: row (low 31 bits, high bits), first spill tile, tiles spanned
+  mutable int64_t fix_count = 0;
   mutable uint16_t *row_rel = nullptr;  // [n + 1] row starts relative to their tile (spmv.hpp: row_rel_kernel); built lazily
   // plan statistics (tile_lb[ntiles+1], [ntiles+2]), read back once by the first product
   mutable int64_t spill_max = -1;      // longest first spill
@@ -295,6 +297,7 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->tile_lb);
   dfree(ctx, b->head);
   dfree(ctx, b->row_rel);
+  dfree(ctx, b->fix_list);
   dfree(ctx, b->col16);
   dfree(ctx, b->tile_c0);
   dfree(ctx, b->col_hot);

@@ -308,6 +308,48 @@ __global__ __launch_bounds__(kBlock) void spmv_fixup_kernel(const int64_t *__res
   y[r] = acc;
 }
 
+// The same fold from a list made once per record (fixup_list_kernel): entry i = a row whose first spill enters tile
+// fix_tile[i] and runs through fix_span[i] tiles.  Two dependent hops (list -> y / head) instead of the four of
+// spmv_fixup_kernel (tile_lb -> row_ptr -> y / head): the launch sits between two SpMV steps of a solver, so its
+// latency is all it costs.
+template <class T>
+__global__ __launch_bounds__(kBlock) void spmv_fixup_list_kernel(const int32_t *__restrict__ fix_row_lo,
+                                                                 const int32_t *__restrict__ fix_row_hi,
+                                                                 const int32_t *__restrict__ fix_tile,
+                                                                 const int32_t *__restrict__ fix_span, int64_t count,
+                                                                 const T *__restrict__ head, T *__restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const int64_t r = ((int64_t)fix_row_hi[i] << 31) | (int64_t)fix_row_lo[i];
+  const int64_t t = fix_tile[i];
+  const int span = fix_span[i];
+  T acc = y[r];
+  T h0 = head[t];
+  for (int u = 1; u < span; u++) { acc = (T)(acc + h0); h0 = head[t + u]; }
+  y[r] = (T)(acc + h0);
+}
+
+template <int TILE>
+__global__ __launch_bounds__(kBlock) void fixup_list_kernel(const int64_t *__restrict__ row_ptr,
+                                                            const int64_t *__restrict__ tile_lb, int64_t ntiles,
+                                                            int32_t *__restrict__ fix_row_lo, int32_t *__restrict__ fix_row_hi,
+                                                            int32_t *__restrict__ fix_tile, int32_t *__restrict__ fix_span,
+                                                            unsigned long long *__restrict__ count) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x + 1;
+  if (t >= ntiles) return;
+  const int64_t lb = tile_lb[t];
+  if (lb == 0) return;
+  const int64_t base = t * TILE, r = lb - 1, re = row_ptr[lb];
+  if (re <= base || row_ptr[r] < base - TILE) return;  // nothing enters here / an earlier tile is the first spill
+  int64_t span = (re - base + TILE - 1) / TILE;
+  if (t + span > ntiles) span = ntiles - t;
+  const unsigned long long slot = atomicAdd(count, 1ull);
+  fix_row_lo[slot] = (int32_t)(r & 0x7fffffff);
+  fix_row_hi[slot] = (int32_t)(r >> 31);
+  fix_tile[slot] = (int32_t)t;
+  fix_span[slot] = (int32_t)span;
+}
+
 // LANES lanes per row, rows dealt to lane groups in order.
 template <class T, class I, int LANES>
 __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(const int64_t *__restrict__ row_ptr,
@@ -797,6 +839,21 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
                          (const int64_t *)a->row_ptr, a->n, a->tile, a->ntiles, rel);
       SAMD_LAUNCH_CHECK(ctx);
       a->row_rel = rel;
+      // the list of rows the fix-up launch folds (one-off, one host synchronisation for its length)
+      if (a->ntiles > 1 && a->ntiles < 0x7fffffffLL) {
+        Tmp<int32_t> fl(ctx);
+        SAMD_TRY(fl.get(4 * a->ntiles));
+        SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+        hipLaunchKernelGGL((fixup_list_kernel<kSpmvTile>), dim3((unsigned)cdiv(a->ntiles - 1, kBlock)), dim3(kBlock), 0,
+                           ctx->stream, (const int64_t *)a->row_ptr, (const int64_t *)a->tile_lb, a->ntiles, fl.p,
+                           fl.p + a->ntiles, fl.p + 2 * a->ntiles, fl.p + 3 * a->ntiles,
+                           reinterpret_cast<unsigned long long *>(ctx->d_small));
+        SAMD_LAUNCH_CHECK(ctx);
+        int64_t cnt = 0;
+        SAMD_TRY(read_small(ctx, ctx->d_small, 1, &cnt));
+        a->fix_count = cnt;
+        a->fix_list = fl.release();
+      }
     }
 #define SAMD_SPMV_LAUNCH(INL, UU)                                                                                  \
   hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, INL, UU>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,   \
@@ -811,7 +868,15 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     }
 #undef SAMD_SPMV_LAUNCH
     SAMD_LAUNCH_CHECK(ctx);
-    if (a->ntiles > 1 && !(inl && a->spill_max <= kSpillInline)) {
+    if (!inl && a->fix_list) {
+      if (a->fix_count > 0) {
+        hipLaunchKernelGGL((spmv_fixup_list_kernel<T>), dim3((unsigned)cdiv(a->fix_count, kBlock)), dim3(kBlock), 0, ctx->stream,
+                           (const int32_t *)a->fix_list, (const int32_t *)(a->fix_list + a->ntiles),
+                           (const int32_t *)(a->fix_list + 2 * a->ntiles), (const int32_t *)(a->fix_list + 3 * a->ntiles),
+                           a->fix_count, (const T *)head, y);
+        SAMD_LAUNCH_CHECK(ctx);
+      }
+    } else if (a->ntiles > 1 && !(inl && a->spill_max <= kSpillInline)) {
       hipLaunchKernelGGL((spmv_fixup_kernel<T, kSpmvTile>), dim3((unsigned)cdiv(a->ntiles - 1, kBlock)), dim3(kBlock),
                          0, ctx->stream, (const int64_t *)a->row_ptr, (const int64_t *)a->tile_lb,
                          (const T *)head, y, a->ntiles, inl);
