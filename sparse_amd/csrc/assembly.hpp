@@ -80,6 +80,17 @@ __global__ __launch_bounds__(kBlock) void concat_vals_kernel(const T *__restrict
   else if (i < na + nb) out[i] = negate_b ? (T)((T)(-1) * b[i - na]) : b[i - na];  // scale (T.i64 (-1)), :183
 }
 
+// how many of 16 * kBlock evenly spread neighbour pairs are in ascending order (is the input nearly sorted?)
+template <class K>
+__global__ __launch_bounds__(kBlock) void ascending_sample_kernel(const K *__restrict__ keys, int64_t count,
+                                                                  unsigned long long *__restrict__ out) {
+  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x, total = (int64_t)gridDim.x * kBlock;
+  const int64_t i = (count - 1) / total * s;
+  unsigned long long ok = (i + 1 < count && keys[i] <= keys[i + 1]) ? 1 : 0;
+  ok = wave_reduce(ok, OpAdd());
+  if ((threadIdx.x & 63) == 0 && ok) atomicAdd(out, ok);
+}
+
 // ---------------------------------------------------------------- merge / emit
 template <class K>
 struct HeadFlagIn {
@@ -190,23 +201,51 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
 
   int64_t merged = 0;
   if (count > 0) {
-    constexpr bool kIndirect = sizeof(T) > 4;  // see radix_sort.hpp, "Payload"
+    // Payload (radix_sort.hpp): 4-byte values travel with their keys.  8-byte values either travel too (16-byte
+    // pairs through every pass) or are represented by their 4-byte source index and gathered once at the end.
+    // Measured both ways on MI355X: the gather is one random 64-byte line per value when the input order is
+    // random (C2 shuffled: merge_emit 2.5 ms of 7.8) and nearly free when the input is already almost in order
+    // (C4 row-major input, conversions of a sorted record); carrying costs 4 extra bytes per pair and pass.  So:
+    // values travel when there are at least 5 passes over a large input whose keys are NOT mostly ascending
+    // (sampled; one small read-back).  C2 assembly 7.8 -> 7.35 ms; C4 stays at 2.3, conversions unchanged.
+    // Option sort_indirect: 1 always by index, -1 never.
+    bool indirect = sizeof(T) > 4;
+    if (sizeof(T) > 4 && ctx->opt_sort_indirect < 0) indirect = false;
+    if (sizeof(T) > 4 && ctx->opt_sort_indirect == 0 && count >= (1 << 20) && end_bit - begin_bit > 32) {
+      SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+      hipLaunchKernelGGL((ascending_sample_kernel<K>), dim3(16), dim3(kBlock), 0, ctx->stream, (const K *)keys.p, count,
+                         reinterpret_cast<unsigned long long *>(ctx->d_small));
+      SAMD_LAUNCH_CHECK(ctx);
+      int64_t asc = 0;
+      SAMD_TRY(read_small(ctx, ctx->d_small, 1, &asc));
+      indirect = asc * 10 >= 16 * kBlock * 9;  // at least 90 % of the sampled neighbours ascend
+    }
+    typedef typename BitsOf<T>::type VB;
     Tmp<K> keys_b(ctx);
     Tmp<uint32_t> pay_a(ctx), pay_b(ctx), slot(ctx);
+    Tmp<VB> val_a(ctx), val_b(ctx);
     SAMD_TRY(keys_b.get(count));
-    SAMD_TRY(pay_a.get(count));
-    SAMD_TRY(pay_b.get(count));
     SAMD_TRY(slot.get(count));
     K *ks = nullptr;
-    const uint32_t *sorted_pay = nullptr;
+    const uint32_t *perm = nullptr;
+    const T *vs = nullptr;
     SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 2, 0, sizeof(int64_t), ctx->stream));
-    SAMD_TRY((radix_sort_pairs<K, uint32_t>(ctx, keys.p, keys_b.p,
-                                             kIndirect ? (const uint32_t *)nullptr
-                                                       : reinterpret_cast<const uint32_t *>(vals_in),
-                                             pay_a.p, pay_b.p, count, begin_bit, end_bit, &ks, &sorted_pay,
-                                             (int *)(ctx->d_small + 2))));
-    const uint32_t *perm = kIndirect ? sorted_pay : nullptr;
-    const T *vs = kIndirect ? vals_in : reinterpret_cast<const T *>(sorted_pay);
+    if (indirect) {
+      const uint32_t *sorted_pay = nullptr;
+      SAMD_TRY(pay_a.get(count));
+      SAMD_TRY(pay_b.get(count));
+      SAMD_TRY((radix_sort_pairs<K, uint32_t>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p, count,
+                                               begin_bit, end_bit, &ks, &sorted_pay, (int *)(ctx->d_small + 2))));
+      perm = sorted_pay;
+      vs = vals_in;
+    } else {
+      const VB *sorted_val = nullptr;
+      SAMD_TRY(val_a.get(count));
+      SAMD_TRY(val_b.get(count));
+      SAMD_TRY((radix_sort_pairs<K, VB>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in), val_a.p, val_b.p,
+                                        count, begin_bit, end_bit, &ks, &sorted_val, (int *)(ctx->d_small + 2))));
+      vs = reinterpret_cast<const T *>(sorted_val);
+    }
 
     // head flags -> slots; total -> host (the only synchronisation of an assembly)
     uint32_t *slots = slot.p;
@@ -228,12 +267,12 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     const unsigned grid = (unsigned)cdiv(count, kBlock);
     if (use_col32(ctx, n_minor)) {
       SAMD_TRY(dalloc(ctx, &b->col32, merged));
-      hipLaunchKernelGGL((merge_emit_kernel<K, T, int32_t, kIndirect>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((merge_emit_kernel<K, T, int32_t, true>), dim3(grid), dim3(kBlock), 0, ctx->stream,
                          (const K *)ks, perm, (const uint32_t *)slots, vs, count, minor_bits, minor_mask, b->col32,
                          b->vals, b->row_ptr);
     } else {
       SAMD_TRY(dalloc(ctx, &b->col64, merged));
-      hipLaunchKernelGGL((merge_emit_kernel<K, T, int64_t, kIndirect>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((merge_emit_kernel<K, T, int64_t, true>), dim3(grid), dim3(kBlock), 0, ctx->stream,
                          (const K *)ks, perm, (const uint32_t *)slots, vs, count, minor_bits, minor_mask, b->col64,
                          b->vals, b->row_ptr);
     }

@@ -690,6 +690,7 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmm_algo")) ctx->opt_spmm_algo = value;
   else if (!strcmp(key, "spmv_cblk")) ctx->opt_spmv_cblk = value;
   else if (!strcmp(key, "sort_algo")) ctx->opt_sort_algo = value;
+  else if (!strcmp(key, "sort_indirect")) ctx->opt_sort_indirect = value;
   else if (!strcmp(key, "spmv_reorder")) ctx->opt_spmv_reorder = value;
   else if (!strcmp(key, "spmv_col16")) ctx->opt_spmv_col16 = value;
   else if (!strcmp(key, "spmv_pb")) ctx->opt_spmv_pb = value;

@@ -123,6 +123,7 @@ struct futhark_context {
                                                                                  // 32-column lines per block, entries per panel
   int64_t opt_spmv_2d = 0;  // 2-D blocked SpMV (spmv_2d.hpp): 0 large skewed records of 4-byte values, 2 always (tests), -1 never
   int64_t opt_spmv_2d_rows = 0, opt_spmv_2d_cols = 0, opt_spmv_2d_entries = 0, opt_spmv_2d_dense = 0;  // test / lab overrides
+  int64_t opt_sort_indirect = 0;  // lab: 1 = assembly sorts 8-byte values by 4-byte source index and gathers them at the end
   int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
   int64_t opt_noalloc_scratch_bytes = 0;  // tests: treat the static scratch array as this small (0 = its real size)
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
