@@ -263,7 +263,7 @@ class ExchangePlan:
             return x_ext
         own = x_ext[self.own_offset:self.own_offset + self.n_own]
         if self.mode == "allgather":
-            if self.equal_slices:
+            if self.equal_slices and getattr(self, "allgather_impl", "collective") == "collective":
                 # the collective's input may not alias its output: a staging buffer made once per x_ext (no
                 # allocation per product), filled by a device copy on the same stream
                 key = (x_ext.data_ptr(), x_ext.dtype, tuple(x_ext.shape))
@@ -272,14 +272,22 @@ class ExchangePlan:
                 self._stage.copy_(own)
                 dist.all_gather_into_tensor(x_ext, self._stage)
                 return x_ext
-            ops = []
-            for p in range(self.world):
-                if p == self.rank:
-                    continue
-                ops.append(dist.P2POp(dist.isend, own, p))
-                ops.append(dist.P2POp(dist.irecv, x_ext[self.bounds[p]:self.bounds[p + 1]], p))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            # all pairs at once: every rank sends its slice to every other rank directly (xGMI is a mesh of
+            # point-to-point links; a ring all-gather is bound by one link).  The transfer list is made once.
+            key = (x_ext.data_ptr(), x_ext.dtype, tuple(x_ext.shape))
+            if getattr(self, "_ag_key", None) != key:
+                ops = []
+                for p in range(self.world):
+                    if p == self.rank:
+                        continue
+                    if self.n_own:
+                        ops.append(dist.P2POp(dist.isend, own, p))
+                    if self.bounds[p + 1] > self.bounds[p]:
+                        ops.append(dist.P2POp(dist.irecv, x_ext[self.bounds[p]:self.bounds[p + 1]], p))
+                self._ag_ops, self._ag_key = ops, key
+            if self._ag_ops:
+                for w in dist.batch_isend_irecv(self._ag_ops):
+                    w.wait()
             return x_ext
         for w in self.exchange_start(x_ext):
             w.wait()
@@ -417,6 +425,35 @@ class DistCsr:
         if x_own is not None and x_own.data_ptr() != self.x_own.data_ptr():
             self.x_own.copy_(x_own)
         return self.plan.exchange(self.x_ext)
+
+    def tune_exchange(self, reps=5):
+        """All-gather mode with equal slices can move x by one RCCL collective or by grouped point-to-point
+        transfers (all pairs at once).  Which is faster depends on the algorithm RCCL picks for the size
+        (a ring is bound by one xGMI link, the all-pairs form uses all seven), so both are timed here, a few
+        exchanges each, and every rank adopts the same winner (max over ranks).  Returns {impl: seconds}."""
+        import time
+        import torch
+        plan, dist = self.plan, self.plan.dist
+        if plan.mode != "allgather" or not plan.equal_slices or dist is None:
+            return {}
+        on_gpu = self.x_ext.is_cuda
+        res = {}
+        for impl in ("collective", "p2p"):
+            plan.allgather_impl = impl
+            plan.exchange(self.x_ext)                       # warm-up (connections, transfer list)
+            if on_gpu:
+                torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                plan.exchange(self.x_ext)
+            if on_gpu:
+                torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.x_ext.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res[impl] = float(t.item()) / reps
+        plan.allgather_impl = min(res, key=res.get)
+        return res
 
     def local_smvm(self, x_ext=None):
         """The dominant kernel alone: this rank's rows against data already in place.  Returns the

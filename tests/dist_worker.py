@@ -39,6 +39,13 @@ def run_case(name, n, r, c, v, force_mode, bounds=None):
     plan.exchange(x_ext)
     y = O.sr_smvm(L, x_ext.numpy())
     assert np.array_equal(y, y_ref[lo:hi]), (name, rank, plan.mode)
+    if plan.mode == "allgather":                       # the all-pairs form of the same exchange
+        plan.allgather_impl = "p2p"
+        x_ext[:lo].zero_()
+        x_ext[hi:].zero_()
+        plan.exchange(x_ext)
+        assert np.array_equal(O.sr_smvm(L, x_ext.numpy()), y_ref[lo:hi]), (name, rank, "p2p all-gather")
+        plan.allgather_impl = "collective"
     # a second exchange after x changed must refresh the remote entries
     x2 = 2.0 * x
     x_own.copy_(torch.from_numpy(x2[lo:hi]))
