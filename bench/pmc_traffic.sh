@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
 mkdir -p $OUT
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  timeout -s KILL 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/$tag -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/$tag.log 2>&1 || { echo "pass $tag failed"; tail -5 $OUT/$tag.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/$tag -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-c5 > $OUT/$tag.log 2>&1 || { echo "pass $tag failed"; tail -5 $OUT/$tag.log; exit 1; }
 done
 python3 - $OUT <<'PY'
 import csv, json, sys, collections, os
@@ -24,7 +24,7 @@ m = {k: v[0] / v[1] for k, v in acc.items()}
 read_b = 2 * m["FETCH_SIZE"] * 1024          # gfx950: 128-B read requests are tallied at 64 B
 write_b = m["WRITE_SIZE"] * 1024
 res = {
-    "command": "bench/pmc_traffic.sh: rocprofv3 --pmc <counter> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline (one pass per counter group)",
+    "command": "bench/pmc_traffic.sh: rocprofv3 --pmc <counter> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-c5 (one pass per counter group)",
     "kernel": kname + " on the C2 workload (5-point Laplacian 4096^2, f64)",
     "dispatches_averaged": acc["FETCH_SIZE"][1],
     "FETCH_SIZE_KB_raw": m["FETCH_SIZE"], "WRITE_SIZE_KB": m["WRITE_SIZE"],
