@@ -518,9 +518,8 @@ int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
     return 0;
   }
   // Large, wide, skewed: for 4-byte values the two-pass product with the x and y slices in LDS is faster than any
-  // renumbering (C3: 1.65 against 2.08 ms) -- if the record qualifies it takes over and nothing more is built here.
-  // Large, wide, skewed: with 4-byte values the 2-D blocked product (x and y slices in LDS together, no product
-  // stream) comes first; what it declines goes to the two-pass product.
+  // renumbering (C3: 1.25 against 2.08 ms) -- if the record qualifies it takes over and nothing more is built here.
+  // The 2-D blocked product is asked first but only accepts when option spmv_2d > 0 (measured slower: 2.3 ms).
   if (!force && a->tb_state == 0) {
     if (tb_prepare<T>(ctx, a, true) != 0) { dfree(ctx, hot_perm); return 1; }
     if (a->tb_state == 1) { dfree(ctx, hot_perm); return 0; }
