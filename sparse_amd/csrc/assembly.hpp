@@ -18,7 +18,7 @@
 //             rows 0..r = row_off[r].
 #pragma once
 
-#include "radix_sort.hpp"
+#include "radix_sort_msd.hpp"
 
 namespace samd {
 
@@ -80,15 +80,21 @@ __global__ __launch_bounds__(kBlock) void concat_vals_kernel(const T *__restrict
   else if (i < na + nb) out[i] = negate_b ? (T)((T)(-1) * b[i - na]) : b[i - na];  // scale (T.i64 (-1)), :183
 }
 
-// how many of 16 * kBlock evenly spread neighbour pairs are in ascending order (is the input nearly sorted?)
+// How far from its place in the sorted order does an input pair sit?  Sum over 16 * kBlock evenly spread
+// pairs of |i - key[i] / keyspace * count| (the rank a key would have if keys were spread evenly), each
+// capped at `cap`.  Small for inputs that are sorted, nearly sorted, or a banded record being transposed
+// (key = column, position ~ row): the final gather vals[perm[i]] then stays inside a cache-sized window.
 template <class K>
-__global__ __launch_bounds__(kBlock) void ascending_sample_kernel(const K *__restrict__ keys, int64_t count,
-                                                                  unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void displacement_sample_kernel(const K *__restrict__ keys, int64_t count,
+                                                                     double inv_keyspace, unsigned long long cap,
+                                                                     unsigned long long *__restrict__ out) {
   const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x, total = (int64_t)gridDim.x * kBlock;
   const int64_t i = (count - 1) / total * s;
-  unsigned long long ok = (i + 1 < count && keys[i] <= keys[i + 1]) ? 1 : 0;
-  ok = wave_reduce(ok, OpAdd());
-  if ((threadIdx.x & 63) == 0 && ok) atomicAdd(out, ok);
+  const double pred = (double)keys[i] * inv_keyspace * (double)count;
+  const double d = fabs(pred - (double)i);
+  unsigned long long v = d >= (double)cap ? cap : (unsigned long long)d;
+  v = wave_reduce(v, OpAdd());
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
 }
 
 // ---------------------------------------------------------------- merge / emit
@@ -189,9 +195,13 @@ inline bool use_col32(futhark_context *ctx, int64_t m) { return !ctx->opt_wide_c
 // [begin_bit, end_bit); bits below begin_bit must already be in order within
 // equal upper bits (the CSR->CSC conversion uses that).  err_flag (device int,
 // may be null) is checked at the one host synchronisation point.
+// allow_msd: the caller can pack the keys again; the sort may then try radix_sort_msd.hpp and, if a chunk did not
+// fit, this returns kAssembleAgain with nothing built (the keys are spent): pack again and call with false.
+constexpr int kAssembleAgain = -77;
 template <class K, class T>
 int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_bit, int end_bit, int minor_bits,
-                  const T *vals_in, int64_t n_major, int64_t n_minor, const int *err_flag, CsrBody<T> **out) {
+                  const T *vals_in, int64_t n_major, int64_t n_minor, const int *err_flag, CsrBody<T> **out,
+                  bool allow_msd = false) {
   CsrBody<T> *b = new CsrBody<T>();
   CsrGuard<T> guard(ctx, b);
   b->n = n_major;
@@ -203,24 +213,27 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
   if (count > 0) {
     // Payload (radix_sort.hpp): 4-byte values travel with their keys.  8-byte values either travel too (16-byte
     // pairs through every pass) or are represented by their 4-byte source index and gathered once at the end.
-    // Measured both ways on MI355X: the gather is one random 64-byte line per value when the input order is
-    // random (C2 shuffled: merge_emit 2.5 ms of 7.8) and nearly free when the input is already almost in order
-    // (C4 row-major input, conversions of a sorted record); carrying costs 4 extra bytes per pair and pass.  So:
-    // values travel when there are at least 5 passes over a large input whose keys are NOT mostly ascending
-    // (sampled; one small read-back).  C2 assembly 7.8 -> 7.35 ms; C4 stays at 2.3, conversions unchanged.
-    // Option sort_indirect: 1 always by index, -1 never.
+    // Measured both ways on MI355X: the gather is one random 64-byte line per value when the sorted order has
+    // nothing to do with the input order (C2 shuffled: merge_emit 2.5 ms of 7.8; C5's CSR->CSC: 28 of 65 ms) and
+    // nearly free when every value ends up near where it started (row-major input, conversions of banded
+    // records); carrying costs 4 extra bytes per pair and pass (C2: 0.24 ms per pass).  So: values travel when
+    // the input is large and a sample of pairs sits far from its sorted place (mean distance beyond a 1 MB window
+    // of values; one small read-back).  Option sort_indirect: 1 always by index, -1 never.
+    typedef typename BitsOf<T>::type VB;
     bool indirect = sizeof(T) > 4;
     if (sizeof(T) > 4 && ctx->opt_sort_indirect < 0) indirect = false;
-    if (sizeof(T) > 4 && ctx->opt_sort_indirect == 0 && count >= (1 << 20) && end_bit - begin_bit > 32) {
+    if (sizeof(T) > 4 && ctx->opt_sort_indirect == 0 && count >= (1 << 20) && end_bit - begin_bit > 16) {
       SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
-      hipLaunchKernelGGL((ascending_sample_kernel<K>), dim3(16), dim3(kBlock), 0, ctx->stream, (const K *)keys.p, count,
-                         reinterpret_cast<unsigned long long *>(ctx->d_small));
+      const double keyspace = ldexp((double)(n_major > 0 ? n_major : 1), minor_bits);
+      const unsigned long long cap = (unsigned long long)count;
+      hipLaunchKernelGGL((displacement_sample_kernel<K>), dim3(16), dim3(kBlock), 0, ctx->stream, (const K *)keys.p,
+                         count, 1.0 / keyspace, cap, reinterpret_cast<unsigned long long *>(ctx->d_small));
       SAMD_LAUNCH_CHECK(ctx);
-      int64_t asc = 0;
-      SAMD_TRY(read_small(ctx, ctx->d_small, 1, &asc));
-      indirect = asc * 10 >= 16 * kBlock * 9;  // at least 90 % of the sampled neighbours ascend
+      int64_t far = 0;
+      SAMD_TRY(read_small(ctx, ctx->d_small, 1, &far));
+      const double mean = (double)far / (16.0 * kBlock);
+      indirect = mean * sizeof(T) <= (double)(1 << 20);
     }
-    typedef typename BitsOf<T>::type VB;
     Tmp<K> keys_b(ctx);
     Tmp<uint32_t> pay_a(ctx), pay_b(ctx), slot(ctx);
     Tmp<VB> val_a(ctx), val_b(ctx);
@@ -229,21 +242,39 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     K *ks = nullptr;
     const uint32_t *perm = nullptr;
     const T *vs = nullptr;
-    SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 2, 0, sizeof(int64_t), ctx->stream));
+    // fewer trips through HBM when the key's top bits cut the input into small even buckets (radix_sort_msd.hpp)
+    int msd_tb = -1;
+    uint32_t msd_ch = 0;
+    if (allow_msd)
+      SAMD_TRY(msd_choose<K>(ctx, keys.p, count, begin_bit, end_bit,
+                             indirect ? RlCfg<K, uint32_t>::kCap : RlCfg<K, VB>::kCap, &msd_tb, &msd_ch));
+    ctx->last_sort_msd = msd_tb >= 0 ? end_bit - msd_tb : 0;
+    SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 2, 0, 2 * sizeof(int64_t), ctx->stream));
+    int *sort_err = (int *)(ctx->d_small + 2), *oversize = (int *)(ctx->d_small + 3);
     if (indirect) {
       const uint32_t *sorted_pay = nullptr;
       SAMD_TRY(pay_a.get(count));
       SAMD_TRY(pay_b.get(count));
-      SAMD_TRY((radix_sort_pairs<K, uint32_t>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p, count,
-                                               begin_bit, end_bit, &ks, &sorted_pay, (int *)(ctx->d_small + 2))));
+      if (msd_tb >= 0)
+        SAMD_TRY((radix_sort_pairs_msd<K, uint32_t>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
+                                                     count, begin_bit, msd_tb, end_bit, msd_ch, &ks, &sorted_pay,
+                                                     sort_err, oversize)));
+      else
+        SAMD_TRY((radix_sort_pairs<K, uint32_t>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
+                                                 count, begin_bit, end_bit, &ks, &sorted_pay, sort_err)));
       perm = sorted_pay;
       vs = vals_in;
     } else {
       const VB *sorted_val = nullptr;
       SAMD_TRY(val_a.get(count));
       SAMD_TRY(val_b.get(count));
-      SAMD_TRY((radix_sort_pairs<K, VB>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in), val_a.p, val_b.p,
-                                        count, begin_bit, end_bit, &ks, &sorted_val, (int *)(ctx->d_small + 2))));
+      if (msd_tb >= 0)
+        SAMD_TRY((radix_sort_pairs_msd<K, VB>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in), val_a.p,
+                                               val_b.p, count, begin_bit, msd_tb, end_bit, msd_ch, &ks, &sorted_val,
+                                               sort_err, oversize)));
+      else
+        SAMD_TRY((radix_sort_pairs<K, VB>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in), val_a.p,
+                                          val_b.p, count, begin_bit, end_bit, &ks, &sorted_val, sort_err)));
       vs = reinterpret_cast<const T *>(sorted_val);
     }
 
@@ -254,9 +285,13 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
                                                                   (uint32_t *)ctx->d_small)));
     if (err_flag)
       SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 1, err_flag, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    int64_t host[3];
-    SAMD_TRY(read_small(ctx, ctx->d_small, 3, host));
+    int64_t host[4];
+    SAMD_TRY(read_small(ctx, ctx->d_small, 4, host));
     if ((int)(host[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
+    if ((int)(host[3] & 0xffffffff) != 0) {  // a chunk of the in-LDS sort did not fit: the order is not final
+      ctx->last_sort_msd = -1;
+      return kAssembleAgain;
+    }
     if ((int)(host[1] & 0xffffffff) != 0)
       return set_error(ctx, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
     merged = (int64_t)(uint32_t)(host[0] & 0xffffffffLL);
@@ -316,12 +351,18 @@ int assemble_coo(futhark_context *ctx, int64_t n_major, int64_t n_minor, const i
   }
   Tmp<uint64_t> keys(ctx);
   SAMD_TRY(keys.get(count));
-  if (count > 0) {
-    hipLaunchKernelGGL((pack_coo_kernel<uint64_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, major, minor, count,
-                       n_major, n_minor, cbits, keys.p, err.p);
-    SAMD_LAUNCH_CHECK(ctx);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (count > 0) {
+      hipLaunchKernelGGL((pack_coo_kernel<uint64_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, major, minor, count,
+                         n_major, n_minor, cbits, keys.p, err.p);
+      SAMD_LAUNCH_CHECK(ctx);
+    }
+    const int rc = assemble_core<uint64_t, T>(ctx, keys, count, 0, rbits + cbits, cbits, vals, n_major, n_minor, err.p,
+                                              out, attempt == 0);
+    if (attempt == 1) ctx->last_sort_msd = -1;  // tried, did not fit, sorted again
+    if (rc != kAssembleAgain) return rc;
   }
-  return assemble_core<uint64_t, T>(ctx, keys, count, 0, rbits + cbits, cbits, vals, n_major, n_minor, err.p, out);
+  return set_error(ctx, "internal: assembly asked to sort again twice");
 }
 
 template <class K, class T, bool SWAP>

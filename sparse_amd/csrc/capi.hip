@@ -691,6 +691,8 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_cblk")) ctx->opt_spmv_cblk = value;
   else if (!strcmp(key, "sort_algo")) ctx->opt_sort_algo = value;
   else if (!strcmp(key, "sort_indirect")) ctx->opt_sort_indirect = value;
+  else if (!strcmp(key, "sort_msd")) ctx->opt_sort_msd = value;
+  else if (!strcmp(key, "sort_msd_chunk")) ctx->opt_sort_msd_chunk = value;
   else if (!strcmp(key, "spmv_reorder")) ctx->opt_spmv_reorder = value;
   else if (!strcmp(key, "spmv_col16")) ctx->opt_spmv_col16 = value;
   else if (!strcmp(key, "spmv_pb")) ctx->opt_spmv_pb = value;
@@ -715,6 +717,8 @@ int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *k
   if (!strcmp(key, "spmm_algo")) return ctx->opt_spmm_algo;
   if (!strcmp(key, "spmv_cblk")) return ctx->opt_spmv_cblk;
   if (!strcmp(key, "sort_algo")) return ctx->opt_sort_algo;
+  if (!strcmp(key, "sort_msd")) return ctx->opt_sort_msd;
+  if (!strcmp(key, "sort_last_msd")) return ctx->last_sort_msd;
   if (!strcmp(key, "spmv_reorder")) return ctx->opt_spmv_reorder;
   if (!strcmp(key, "spmv_pb")) return ctx->opt_spmv_pb;
   if (!strcmp(key, "spmv_2d")) return ctx->opt_spmv_2d;

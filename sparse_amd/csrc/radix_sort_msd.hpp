@@ -1,0 +1,367 @@
+// radix_sort_msd.hpp -- the same stable sort with fewer trips through HBM: the TOP key bits by global passes,
+// everything below them inside LDS.
+//
+// An LSD sort of b key bits moves every pair through HBM b/8 times (C2: 48 bits, six passes, 5.5 of the
+// assembly's 7.5 ms).  Here the top T bits (16 or 24) are sorted first by the ordinary stable passes of
+// radix_sort.hpp, which leaves the pairs grouped into 2^T buckets, input order kept inside each bucket.  When the
+// buckets are small, one more kernel finishes the job: a workgroup takes a chunk of whole consecutive buckets
+// (<= kCap pairs), sorts it by the remaining low bits with in-LDS passes and then, stably, by the ordinal of the
+// bucket inside the chunk, and writes it back in place.  Two or three global passes plus one read and one write.
+//
+// Which T, if any, is decided from a sampled histogram of the top 16 bits (msd_choose): skewed keys (power-law
+// rows) keep the LSD sort.  The estimate can be wrong; a chunk that does not fit its workgroup is copied through
+// unsorted and raises *oversize, which the caller reads at its next synchronisation and answers by sorting
+// again without this file (assembly.hpp).
+#pragma once
+
+#include "radix_sort.hpp"
+
+namespace samd {
+
+template <class K, class P>
+struct RlCfg {
+  // items per thread: key + payload + 2-byte bucket ordinal per pair in LDS, two workgroups per CU (<= 78 KB each)
+  static constexpr int kPair = (int)(sizeof(K) + sizeof(P));
+  static constexpr int kItems = kPair <= 8 ? 28 : (kPair <= 12 ? 20 : 16);
+  static constexpr int kCap = kBlock * kItems;
+};
+
+constexpr int kRlDigitBits = 5;  // in-LDS passes: 32 digits, 16 counter words per thread
+constexpr int kMsdBins = 1 << 16;
+constexpr int64_t kMsdMinCount = 1 << 22;    // below this the passes are launch- and ramp-bound anyway
+constexpr int64_t kMsdSamples = 1 << 21;
+
+// histogram of bits [shift, shift + 16) of every stride-th key.  gate (may be null): the largest bin of an earlier,
+// much smaller sample; if that already shows heavy skew the full sample is skipped -- on power-law keys
+// its adds would pile up on a few addresses (RMAT scale 24: 1.4 ms for 2M samples) and the answer is known.
+// 2^15 samples over the bins in use: even keys stay below their mean + a few deviations
+__host__ __device__ inline bool msd_gate_skewed(unsigned long long mx, unsigned long long used) {
+  return used == 0 || mx * used > 32ull * used + 4ull * 32768ull;
+}
+template <class K>
+__global__ __launch_bounds__(kBlock) void msd_sample_kernel(const K *__restrict__ keys, int64_t count, int64_t stride,
+                                                            int shift, uint32_t *__restrict__ hist,
+                                                            const unsigned long long *__restrict__ gate) {
+  if (gate && msd_gate_skewed(gate[0], gate[1])) return;
+  const int64_t total = (int64_t)gridDim.x * kBlock;
+  const int lane = threadIdx.x & 63;
+  for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s * stride < count; s += total) {
+    const uint32_t bin = (uint32_t)(keys[s * stride] >> shift) & (uint32_t)(kMsdBins - 1);
+    // sorted inputs put a whole wavefront into one bin: one add for all of them
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
+    const uint64_t active = __ballot(true), same = __ballot(bin == first);
+    if (same == active) {
+      if (lane == __builtin_ctzll(active)) atomicAdd(&hist[bin], (uint32_t)__popcll(active));
+    } else {
+      atomicAdd(&hist[bin], 1u);
+    }
+  }
+}
+
+// out[0] = largest bin, out[1] = number of bins in use
+__global__ __launch_bounds__(kBlock) void msd_max_kernel(const uint32_t *__restrict__ hist,
+                                                         unsigned long long *__restrict__ out) {
+  unsigned long long mx = 0, used = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < kMsdBins; i += gridDim.x * kBlock) {
+    const uint32_t h = hist[i];
+    mx = h > mx ? h : mx;
+    used += h ? 1 : 0;
+  }
+  mx = wave_reduce(mx, OpMax());
+  used = wave_reduce(used, OpAdd());
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out, mx);
+    if (used) atomicAdd(out + 1, used);
+  }
+}
+
+// Chooses the number of top bits the global passes take (*tb = first of them; -1 = keep the LSD sort) and the
+// nominal chunk length.  One small read-back.
+template <class K>
+int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit, int end_bit, int cap, int *tb,
+               uint32_t *ch) {
+  *tb = -1;
+  *ch = 0;
+  const int total = end_bit - begin_bit;
+  if (ctx->opt_sort_msd < 0 || count <= 0) return 0;
+  if (ctx->opt_sort_msd > 0) {  // tests and labs: this many top bits, whatever the input
+    int t = (int)ctx->opt_sort_msd;
+    if (t >= total) t = total - 1;
+    if (t < 1) return 0;
+    *tb = end_bit - t;
+    uint32_t c = ctx->opt_sort_msd_chunk > 0 ? (uint32_t)ctx->opt_sort_msd_chunk : (uint32_t)cap / 2;
+    if (c > (uint32_t)cap) c = (uint32_t)cap;
+    *ch = c;
+    return 0;
+  }
+  if (count < kMsdMinCount || total <= 24 || end_bit < 16) return 0;
+  Tmp<uint32_t> hist(ctx);
+  SAMD_TRY(hist.get(2 * kMsdBins));
+  SAMD_HIP(ctx, hipMemsetAsync(hist.p, 0, sizeof(uint32_t) * 2 * kMsdBins, ctx->stream));
+  SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 4, 0, 4 * sizeof(int64_t), ctx->stream));
+  unsigned long long *res = reinterpret_cast<unsigned long long *>(ctx->d_small + 4);  // [max, used, gate max, gate used]
+  const int64_t stride = cdiv(count, kMsdSamples);
+  const int64_t samples = cdiv(count, stride);
+  {
+    // a small sample first; the full one runs only if that one is even
+    const int64_t gstride = cdiv(count, (int64_t)1 << 15);
+    hipLaunchKernelGGL((msd_sample_kernel<K>), dim3((unsigned)cdiv(cdiv(count, gstride), kBlock)), dim3(kBlock), 0,
+                       ctx->stream, keys, count, gstride, end_bit - 16, hist.p + kMsdBins,
+                       (const unsigned long long *)nullptr);
+    SAMD_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(msd_max_kernel, dim3(64), dim3(kBlock), 0, ctx->stream, (const uint32_t *)(hist.p + kMsdBins),
+                       res + 2);
+    SAMD_LAUNCH_CHECK(ctx);
+    const int64_t want = cdiv(samples, kBlock), capg = (int64_t)ctx->num_cu * 16;
+    hipLaunchKernelGGL((msd_sample_kernel<K>), dim3((unsigned)(want < capg ? want : capg)), dim3(kBlock), 0, ctx->stream,
+                       keys, count, stride, end_bit - 16, hist.p, (const unsigned long long *)(res + 2));
+    SAMD_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(msd_max_kernel, dim3(64), dim3(kBlock), 0, ctx->stream, (const uint32_t *)hist.p, res);
+    SAMD_LAUNCH_CHECK(ctx);
+  }
+  int64_t h[4];
+  SAMD_TRY(read_small(ctx, ctx->d_small + 4, 4, h));
+  if (msd_gate_skewed((unsigned long long)h[2], (unsigned long long)h[3]) || h[1] <= 0) return 0;  // skewed at first sight
+  const double per_sample = (double)count / (double)samples;
+  const double max16 = (double)h[0] * per_sample;            // largest 16-bit bucket, estimated (from above)
+  const double avg16 = (double)count / (double)h[1];
+  if (max16 > 4.0 * avg16 + 64.0 * per_sample) return 0;     // skewed: the buckets below would not be even either
+  const double limit = 0.5 * cap;
+  double maxb;
+  int t;
+  if (max16 <= limit) {
+    t = 16;
+    maxb = max16;
+  } else {
+    // the next 8 bits split a bucket into up to 256; allow the finer level to be 4 times less even
+    if (total <= 32) return 0;
+    t = 24;
+    maxb = max16 / 256.0 * 4.0 + 64.0;
+    if (maxb > limit) return 0;
+  }
+  uint32_t c = (uint32_t)cap - (uint32_t)maxb;
+  c &= ~255u;
+  if (c < (uint32_t)cap / 2) c = (uint32_t)cap / 2;
+  *tb = end_bit - t;
+  *ch = c;
+  return 0;
+}
+
+// chunk c = [a[c], a[c+1]): a[c] = the first bucket boundary at or after c * ch
+template <class K>
+__global__ __launch_bounds__(kBlock) void msd_chunk_plan_kernel(const K *__restrict__ keys, uint32_t n, int tb,
+                                                                uint32_t ch, uint32_t nchunks,
+                                                                uint32_t *__restrict__ a) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c > nchunks) return;
+  if (c == nchunks) { a[c] = n; return; }
+  if (c == 0) { a[0] = 0; return; }
+  const uint64_t s = (uint64_t)c * ch;  // < n
+  const K top0 = (K)(keys[s - 1] >> tb);
+  // smallest i in [s, n] with i == n or top(keys[i]) != top0: gallop, then bisect
+  uint64_t f = s - 1, t, step = 1;
+  while (true) {
+    const uint64_t probe = f + step;
+    if (probe >= n) { t = n; break; }
+    if ((K)(keys[probe] >> tb) != top0) { t = probe; break; }
+    f = probe;
+    step *= 2;
+  }
+  while (t - f > 1) {
+    const uint64_t mid = f + (t - f) / 2;
+    if ((K)(keys[mid] >> tb) != top0) t = mid; else f = mid;
+  }
+  a[c] = (uint32_t)t;
+}
+
+// One chunk per workgroup: stable sort by key bits [begin_bit, tb) inside every bucket (= run of equal bits
+// >= tb) of the chunk, i.e. by the composite (ordinal of the bucket in the chunk, low key bits).
+//
+// Pairs live in registers in the BLOCKED arrangement (thread t holds positions t*R .. t*R+R-1, R = rounds the
+// chunk needs), and a pass of DB bits ranks them with thread-private counters: counter (digit, thread) counts the
+// thread's pairs of that digit (one LDS add-with-return per pair, no dependent chain and no ballots), a block-wide
+// scan in (digit, thread) order turns the counters into bases, rank = base + pairs of the same digit earlier in
+// the same thread: stable.  Two 16-bit counters share a word (digits d and d + 2^DB/2), so one scan serves both
+// halves (the upper half gets the lower half's total added).  A ballot-based match-any ranking (as in the global
+// passes) was the first version: 8 ballots and ~60 vector instructions per pair and pass made the kernel
+// compute-bound at 2.2 ms on C2; this one needs ~10.
+// The counters alias the pair buffer: pairs are in registers while counters are live.
+// Addresses are padded by one slot per 32 so that the blocked reads (lane stride R) stay off each other's banks.
+__device__ __forceinline__ uint32_t rl_pad(uint32_t i) { return i + (i >> 5); }
+
+template <class K, class P, int ITEMS, int DB>
+__global__ __launch_bounds__(kBlock) void rs_local_sort(const K *__restrict__ kin, const P *__restrict__ pin,
+                                                        K *__restrict__ kout, P *__restrict__ pout,
+                                                        const uint32_t *__restrict__ chunk_a, int begin_bit, int tb,
+                                                        int *__restrict__ oversize, int lab) {
+  constexpr int CAP = kBlock * ITEMS;
+  constexpr int CAPP = CAP + CAP / 32 + 1;
+  constexpr int NBH = (1 << DB) / 2;                 // counter words per thread (two digits each)
+  constexpr int CW = NBH * kBlock + NBH * kBlock / 32 + 1;
+  constexpr size_t kDataBytes = (size_t)CAPP * (sizeof(K) + sizeof(P) + 2) + 32;
+  constexpr size_t kCntBytes = (size_t)CW * 4;
+  constexpr size_t kRaw = kDataBytes > kCntBytes ? kDataBytes : kCntBytes;
+  __shared__ __align__(16) unsigned char raw[kRaw];
+  __shared__ uint32_t shs[kWaves];
+  K *skey = reinterpret_cast<K *>(raw);
+  P *spay = reinterpret_cast<P *>(raw + (((size_t)CAPP * sizeof(K) + 15) & ~(size_t)15));
+  uint16_t *sord = reinterpret_cast<uint16_t *>(raw + (((size_t)CAPP * sizeof(K) + 15) & ~(size_t)15) +
+                                                (((size_t)CAPP * sizeof(P) + 15) & ~(size_t)15));
+  uint32_t *C = reinterpret_cast<uint32_t *>(raw);
+
+  const int tid = threadIdx.x;
+  const uint32_t a = chunk_a[blockIdx.x], b = chunk_a[blockIdx.x + 1];
+  const uint32_t L = b - a;
+  if (L == 0) return;
+  if (L > (uint32_t)CAP) {  // does not fit: leave the pairs as they are (valid keys, wrong order) and say so
+    if (tid == 0) *oversize = 1;
+    for (uint32_t i = a + tid; i < b; i += kBlock) {
+      kout[i] = kin[i];
+      pout[i] = pin[i];
+    }
+    return;
+  }
+  // coalesced load into LDS, then every thread takes its R consecutive pairs
+  const int R = (int)((L + kBlock - 1) / kBlock);
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const uint32_t i = (uint32_t)k * kBlock + tid;
+    if (k < R && i < L) {
+      skey[rl_pad(i)] = kin[a + i];
+      spay[rl_pad(i)] = pin[a + i];
+    }
+  }
+  __syncthreads();
+  K key[ITEMS];
+  P pay[ITEMS];
+  uint32_t ord[ITEMS], prev[ITEMS];
+  const uint32_t pbase = (uint32_t)tid * (uint32_t)R;
+  uint32_t heads = 0;
+  {
+    K before = (pbase > 0 && pbase < L) ? skey[rl_pad(pbase - 1)] : (K)0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const uint32_t p = pbase + k;
+      const bool live = k < R && p < L;
+      key[k] = live ? skey[rl_pad(p)] : (K)~(K)0;
+      pay[k] = live ? spay[rl_pad(p)] : (P)0;
+      const bool head = live && (p == 0 || (K)(key[k] >> tb) != (K)(before >> tb));
+      heads += head ? 1u : 0u;
+      ord[k] = heads;  // inclusive count inside the thread
+      before = key[k];
+    }
+  }
+  uint32_t nbk;
+  {
+    const uint32_t ex = block_exclusive_add<uint32_t>(heads, shs, nbk);  // ends with a barrier: the buffer is free
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) ord[k] = (k < R && pbase + k < L) ? ex + ord[k] - 1u : 0xffffffffu;
+  }
+  const int lowbits = tb - begin_bit;
+  const int ordbits = nbk > 1 ? 32 - __builtin_clz(nbk - 1) : 0;
+  int passes = (lowbits + ordbits + DB - 1) / DB;
+  if (lab > 0 && passes > lab - 1) passes = lab - 1;  // lab: at most lab - 1 passes (the result is then wrong)
+  const uint64_t lowmask = lowbits >= 64 ? ~0ull : ((1ull << lowbits) - 1ull);
+  for (int pass = 0; pass < passes; pass++) {
+    const int shift = DB * pass;
+    uint32_t dg[ITEMS];
+    // this thread's column of counters: zero, then count (same thread, LDS keeps its order)
+#pragma unroll
+    for (int j = 0; j < NBH; j++) C[rl_pad((uint32_t)j * kBlock + tid)] = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      if (k < R) {
+        const uint64_t comp = ((uint64_t)ord[k] << lowbits) | ((uint64_t)(key[k] >> begin_bit) & lowmask);
+        const uint32_t d = (uint32_t)(comp >> shift) & (uint32_t)((1 << DB) - 1);
+        dg[k] = d;
+        const uint32_t old = atomicAdd(&C[rl_pad((d & (NBH - 1)) * kBlock + tid)], d >= NBH ? 65536u : 1u);
+        prev[k] = d >= NBH ? old >> 16 : old & 0xffffu;
+      }
+    }
+    __syncthreads();
+    // scan in (digit, thread) order: thread s owns the NBH consecutive words from s * NBH
+    {
+      uint32_t w[NBH], sum = 0;
+#pragma unroll
+      for (int q = 0; q < NBH; q++) {
+        w[q] = C[rl_pad((uint32_t)tid * NBH + q)];
+        sum += w[q];
+      }
+      uint32_t total;
+      uint32_t run = block_exclusive_add<uint32_t>(sum, shs, total);
+      run += total << 16;  // digits of the upper halves come after all digits of the lower halves
+#pragma unroll
+      for (int q = 0; q < NBH; q++) {
+        C[rl_pad((uint32_t)tid * NBH + q)] = run;
+        run += w[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      if (k < R) {
+        const uint32_t d = dg[k];
+        const uint32_t word = C[rl_pad((d & (NBH - 1)) * kBlock + tid)];
+        prev[k] += d >= NBH ? word >> 16 : word & 0xffffu;  // = rank
+      }
+    }
+    __syncthreads();  // counters are spent: the buffer takes the pairs
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      if (k < R) {
+        const uint32_t q = rl_pad(prev[k]);
+        skey[q] = key[k];
+        spay[q] = pay[k];
+        sord[q] = (uint16_t)ord[k];
+      }
+    }
+    __syncthreads();
+    if (pass + 1 < passes) {
+#pragma unroll
+      for (int k = 0; k < ITEMS; k++) {
+        if (k < R) {
+          const uint32_t q = rl_pad(pbase + k);
+          key[k] = skey[q];
+          pay[k] = spay[q];
+          const uint32_t o = sord[q];
+          ord[k] = o == 0xffffu ? 0xffffffffu : o;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // dead pairs (all-ones keys and ordinals) ended up behind the L live ones
+  for (uint32_t i = tid; i < L; i += kBlock) {
+    kout[a + i] = skey[rl_pad(i)];
+    pout[a + i] = spay[rl_pad(i)];
+  }
+}
+
+// Sorts like radix_sort_pairs, bits [begin_bit, end_bit), with the bits from tb up by global passes and the rest
+// per chunk.  *oversize (device int, zeroed by the caller) is raised if a chunk did not fit.
+template <class K, class P>
+int radix_sort_pairs_msd(futhark_context *ctx, K *keys_a, K *keys_b, const P *pay_in, P *pay_a, P *pay_b, int64_t n,
+                         int begin_bit, int tb, int end_bit, uint32_t ch, K **keys_out, const P **pay_out,
+                         int *sort_err, int *oversize) {
+  constexpr int ITEMS = RlCfg<K, P>::kItems;
+  K *ks = nullptr;
+  const P *ps = nullptr;
+  SAMD_TRY((radix_sort_pairs<K, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, tb, end_bit, &ks, &ps, sort_err)));
+  if (ps == nullptr || ps == pay_in) return set_error(ctx, "internal: msd sort without a global pass");
+  K *kfree = ks == keys_a ? keys_b : keys_a;
+  P *pfree = ps == pay_a ? pay_b : pay_a;
+  const uint32_t nchunks = (uint32_t)cdiv(n, (int64_t)ch);
+  Tmp<uint32_t> ca(ctx);
+  SAMD_TRY(ca.get((int64_t)nchunks + 1));
+  hipLaunchKernelGGL((msd_chunk_plan_kernel<K>), dim3((unsigned)cdiv((int64_t)nchunks + 1, kBlock)), dim3(kBlock), 0,
+                     ctx->stream, (const K *)ks, (uint32_t)n, tb, ch, nchunks, ca.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL((rs_local_sort<K, P, ITEMS, kRlDigitBits>), dim3(nchunks), dim3(kBlock), 0, ctx->stream, (const K *)ks, ps, kfree,
+                     pfree, (const uint32_t *)ca.p, begin_bit, tb, oversize, (int)ctx->opt_ablate);
+  SAMD_LAUNCH_CHECK(ctx);
+  *keys_out = kfree;
+  *pay_out = pfree;
+  return 0;
+}
+
+}  // namespace samd

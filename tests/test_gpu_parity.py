@@ -146,6 +146,40 @@ def test_sparse_edge_cases(ctx, dtype):
     assert_same_record(M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v))
 
 
+@pytest.mark.parametrize("dtype,indirect", [("f64", 1), ("f64", -1), ("f32", 0), ("i32", 0)])
+@pytest.mark.parametrize("top,chunk", [(4, 0), (8, 700), (12, 0), (16, 2048), (20, 300), (33, 1000)])
+def test_sparse_top_bits_by_global_passes_rest_in_lds(ctx, dtype, indirect, top, chunk):
+    """radix_sort_msd.hpp, forced (option sort_msd = number of top key bits) on inputs the oracle can follow:
+    buckets of thousands of triples down to single ones, chunks cut at bucket boundaries, one or two ordinal
+    passes, and buckets that do not fit a workgroup (top = 4: sixteen buckets of ~19 K): sorted again without it."""
+    n, m, k = 100000, 100000, 300000                      # 34 key bits
+    r, c, v = random_coo(n, m, k, dtype, seed=top * 31 + chunk, dup_frac=0.2)
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    want = O.sr_sparse(n, m, r, c, v)
+    ctx.set_option("sort_msd", top)
+    ctx.set_option("sort_msd_chunk", chunk)
+    ctx.set_option("sort_indirect", indirect)
+    try:
+        assert_same_record(M.sr.sparse(n, m, (r, c, v)), want)
+        assert ctx.get_option("sort_last_msd") == (-1 if top == 4 else top)
+        # sorted and reverse-sorted input, and one coordinate repeated through a whole chunk
+        o = np.lexsort((c, r))
+        for order in (o, o[::-1]):
+            assert_same_record(M.sr.sparse(n, m, (r[order], c[order], v[order])),
+                               O.sr_sparse(n, m, r[order], c[order], v[order]))
+        r2, c2 = r.copy(), c.copy()
+        r2[1000:4000], c2[1000:4000] = 77, 5
+        assert_same_record(M.sr.sparse(n, m, (r2, c2, v)), O.sr_sparse(n, m, r2, c2, v))
+        # a column range past int32: 50 key bits
+        n3, m3 = 1 << 17, 1 << 33
+        c3 = (synth.splitmix64(6, np.arange(k, dtype=np.uint64)) % np.uint64(m3)).astype(np.int64)
+        assert_same_record(M.sr.sparse(n3, m3, (r, c3, v)), O.sr_sparse(n3, m3, r, c3, v))
+    finally:
+        ctx.set_option("sort_msd", 0)
+        ctx.set_option("sort_msd_chunk", 0)
+        ctx.set_option("sort_indirect", 0)
+
+
 def test_sparse_rejects_out_of_range(ctx):
     from sparse_amd.compressed import SparseError
     M = mk(ctx, "f64")
