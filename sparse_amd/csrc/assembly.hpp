@@ -242,39 +242,107 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     K *ks = nullptr;
     const uint32_t *perm = nullptr;
     const T *vs = nullptr;
-    // fewer trips through HBM when the key's top bits cut the input into small even buckets (radix_sort_msd.hpp)
+    // fewer trips through HBM when the key's top bits cut the input into small even buckets (radix_sort_msd.hpp):
+    // top bits by global passes, then one kernel that sorts the rest inside LDS and writes the record itself
     int msd_tb = -1;
     uint32_t msd_ch = 0;
-    if (allow_msd)
-      SAMD_TRY(msd_choose<K>(ctx, keys.p, count, begin_bit, end_bit,
-                             indirect ? RlCfg<K, uint32_t>::kCap : RlCfg<K, VB>::kCap, &msd_tb, &msd_ch));
+    if constexpr (sizeof(K) == 8) {
+      if (allow_msd && begin_bit == 0 && end_bit <= 64 - kRlTagBits)
+        SAMD_TRY(msd_choose<K>(ctx, keys.p, count, begin_bit, end_bit, RlEmitCfg<T>::kCap, &msd_tb, &msd_ch));
+      if (msd_tb > 40) msd_tb = -1;  // composite = ordinal (<= 11 bits) | low bits | 13-bit tag
+    }
     ctx->last_sort_msd = msd_tb >= 0 ? end_bit - msd_tb : 0;
     SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 2, 0, 2 * sizeof(int64_t), ctx->stream));
     int *sort_err = (int *)(ctx->d_small + 2), *oversize = (int *)(ctx->d_small + 3);
+    if constexpr (sizeof(K) == 8) {
+      if (msd_tb >= 0) {
+        SAMD_TRY(dalloc(ctx, &b->vals, count));
+        SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t) * 2, ctx->stream));
+        unsigned long long *merged_dev = reinterpret_cast<unsigned long long *>(ctx->d_small);
+        const bool c32 = use_col32(ctx, n_minor);
+        if (c32) SAMD_TRY(dalloc(ctx, &b->col32, count));
+        else SAMD_TRY(dalloc(ctx, &b->col64, count));
+        if (indirect) {
+          SAMD_TRY(pay_a.get(count));
+          SAMD_TRY(pay_b.get(count));
+          if (c32)
+            SAMD_TRY((msd_sort_emit<T, int32_t, true>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
+                                                       vals_in, count, msd_tb, end_bit, msd_ch, minor_bits, b->col32,
+                                                       b->vals, b->row_ptr, merged_dev, sort_err, oversize)));
+          else
+            SAMD_TRY((msd_sort_emit<T, int64_t, true>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
+                                                       vals_in, count, msd_tb, end_bit, msd_ch, minor_bits, b->col64,
+                                                       b->vals, b->row_ptr, merged_dev, sort_err, oversize)));
+        } else {
+          SAMD_TRY(val_a.get(count));
+          SAMD_TRY(val_b.get(count));
+          if (c32)
+            SAMD_TRY((msd_sort_emit<T, int32_t, false>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in),
+                                                        val_a.p, val_b.p, (const T *)nullptr, count, msd_tb, end_bit,
+                                                        msd_ch, minor_bits, b->col32, b->vals, b->row_ptr, merged_dev,
+                                                        sort_err, oversize)));
+          else
+            SAMD_TRY((msd_sort_emit<T, int64_t, false>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in),
+                                                        val_a.p, val_b.p, (const T *)nullptr, count, msd_tb, end_bit,
+                                                        msd_ch, minor_bits, b->col64, b->vals, b->row_ptr, merged_dev,
+                                                        sort_err, oversize)));
+        }
+        if (err_flag)
+          SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 1, err_flag, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        int64_t host[4];
+        SAMD_TRY(read_small(ctx, ctx->d_small, 4, host));
+        if ((int)(host[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
+        if ((int)(host[1] & 0xffffffff) != 0)
+          return set_error(ctx, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
+        if ((int)(host[3] & 0xffffffff) != 0) {  // a chunk did not fit its workgroup: nothing of this is final
+          ctx->last_sort_msd = -1;
+          return kAssembleAgain;
+        }
+        merged = host[0];
+        b->nnz = merged;
+        if (merged * 4 < count * 3) {  // many duplicates: do not keep count-sized arrays for the record's lifetime
+          T *v2 = nullptr;
+          SAMD_TRY(dalloc(ctx, &v2, merged));
+          SAMD_HIP(ctx, hipMemcpyAsync(v2, b->vals, sizeof(T) * (size_t)merged, hipMemcpyDeviceToDevice, ctx->stream));
+          dfree(ctx, b->vals);
+          b->vals = v2;
+          if (c32) {
+            int32_t *c2 = nullptr;
+            SAMD_TRY(dalloc(ctx, &c2, merged));
+            SAMD_HIP(ctx, hipMemcpyAsync(c2, b->col32, sizeof(int32_t) * (size_t)merged, hipMemcpyDeviceToDevice, ctx->stream));
+            dfree(ctx, b->col32);
+            b->col32 = c2;
+          } else {
+            int64_t *c2 = nullptr;
+            SAMD_TRY(dalloc(ctx, &c2, merged));
+            SAMD_HIP(ctx, hipMemcpyAsync(c2, b->col64, sizeof(int64_t) * (size_t)merged, hipMemcpyDeviceToDevice, ctx->stream));
+            dfree(ctx, b->col64);
+            b->col64 = c2;
+          }
+        }
+        if (n_major > 0)
+          SAMD_TRY((device_scan<int64_t, OpMax, PtrIn<int64_t>, false>(ctx, PtrIn<int64_t>{b->row_ptr + 1}, n_major,
+                                                                        (int64_t)0, OpMax(), b->row_ptr + 1,
+                                                                        (int64_t *)nullptr)));
+        SAMD_TRY(build_plan(ctx, b));
+        *out = guard.release();
+        return 0;
+      }
+    }
     if (indirect) {
       const uint32_t *sorted_pay = nullptr;
       SAMD_TRY(pay_a.get(count));
       SAMD_TRY(pay_b.get(count));
-      if (msd_tb >= 0)
-        SAMD_TRY((radix_sort_pairs_msd<K, uint32_t>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
-                                                     count, begin_bit, msd_tb, end_bit, msd_ch, &ks, &sorted_pay,
-                                                     sort_err, oversize)));
-      else
-        SAMD_TRY((radix_sort_pairs<K, uint32_t>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
-                                                 count, begin_bit, end_bit, &ks, &sorted_pay, sort_err)));
+      SAMD_TRY((radix_sort_pairs<K, uint32_t>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p, count,
+                                               begin_bit, end_bit, &ks, &sorted_pay, sort_err)));
       perm = sorted_pay;
       vs = vals_in;
     } else {
       const VB *sorted_val = nullptr;
       SAMD_TRY(val_a.get(count));
       SAMD_TRY(val_b.get(count));
-      if (msd_tb >= 0)
-        SAMD_TRY((radix_sort_pairs_msd<K, VB>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in), val_a.p,
-                                               val_b.p, count, begin_bit, msd_tb, end_bit, msd_ch, &ks, &sorted_val,
-                                               sort_err, oversize)));
-      else
-        SAMD_TRY((radix_sort_pairs<K, VB>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in), val_a.p,
-                                          val_b.p, count, begin_bit, end_bit, &ks, &sorted_val, sort_err)));
+      SAMD_TRY((radix_sort_pairs<K, VB>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in), val_a.p, val_b.p,
+                                        count, begin_bit, end_bit, &ks, &sorted_val, sort_err)));
       vs = reinterpret_cast<const T *>(sorted_val);
     }
 
@@ -288,10 +356,6 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     int64_t host[4];
     SAMD_TRY(read_small(ctx, ctx->d_small, 4, host));
     if ((int)(host[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
-    if ((int)(host[3] & 0xffffffff) != 0) {  // a chunk of the in-LDS sort did not fit: the order is not final
-      ctx->last_sort_msd = -1;
-      return kAssembleAgain;
-    }
     if ((int)(host[1] & 0xffffffff) != 0)
       return set_error(ctx, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
     merged = (int64_t)(uint32_t)(host[0] & 0xffffffffLL);

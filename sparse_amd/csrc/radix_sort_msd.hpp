@@ -14,9 +14,22 @@
 // again without this file (assembly.hpp).
 #pragma once
 
+#include <type_traits>
+
 #include "radix_sort.hpp"
 
 namespace samd {
+
+template <class T> struct RlBits;
+template <> struct RlBits<double> { typedef uint64_t type; };
+template <> struct RlBits<float> { typedef uint32_t type; };
+template <> struct RlBits<int32_t> { typedef uint32_t type; };
+template <class T>
+__device__ __forceinline__ T rl_from_bits(typename RlBits<T>::type v) {
+  T out;
+  __builtin_memcpy(&out, &v, sizeof(T));
+  return out;
+}
 
 template <class K, class P>
 struct RlCfg {
@@ -26,7 +39,7 @@ struct RlCfg {
   static constexpr int kCap = kBlock * kItems;
 };
 
-constexpr int kRlDigitBits = 5;  // in-LDS passes: 32 digits, 16 counter words per thread
+constexpr int kRlDigitBits = 5;  // in-LDS passes: 32 digits, 16 counter words per thread (6 bits: one pass fewer on C2, same time)
 constexpr int kMsdBins = 1 << 16;
 constexpr int64_t kMsdMinCount = 1 << 22;    // below this the passes are launch- and ramp-bound anyway
 constexpr int64_t kMsdSamples = 1 << 21;
@@ -87,6 +100,7 @@ int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit
   if (ctx->opt_sort_msd > 0) {  // tests and labs: this many top bits, whatever the input
     int t = (int)ctx->opt_sort_msd;
     if (t >= total) t = total - 1;
+    if (t > 32) t = 32;  // top_tab keeps a bucket's top bits in 32
     if (t < 1) return 0;
     *tb = end_bit - t;
     uint32_t c = ctx->opt_sort_msd_chunk > 0 ? (uint32_t)ctx->opt_sort_msd_chunk : (uint32_t)cap / 2;
@@ -337,6 +351,316 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort(const K *__restrict__ ki
   }
 }
 
+// ------------------------------------------------------------------ in-LDS sort fused with the record's emission
+// The assembly's own version of the kernel above (assembly.hpp calls it; begin_bit = 0): the chunk is sorted as
+// 8-byte composites (bucket ordinal | low key bits | 13-bit position in the chunk) -- payloads stay where they
+// were loaded and are fetched by position at the end, so a pass moves 8 bytes per pair instead of 18 -- and the
+// sorted chunk never goes back to HBM as pairs: duplicates (equal composites above the tag; they cannot span
+// chunks, a chunk being whole buckets) are folded left to right, the chunk's first output slot comes from a
+// decoupled look-back over the chunks before it (one status word per chunk, tickets as in rs_onesweep), and the
+// workgroup writes col_idx / vals / row ends directly.  Replaces head-flag scan + merge_emit (C2: 0.95 ms) and the
+// 16-byte write + 20-byte read between them.
+constexpr int kRlTagBits = 13;
+constexpr int kRlMaxBuckets = 2048;   // bucket ordinals per chunk (top_tab); more = the chunk is refused like an oversize one
+
+// Look-back by one whole wavefront (all 64 lanes call it): 64 predecessors per step instead of one -- the first
+// 512 chunks of a launch start together and finish together, and a lane-by-lane walk over them was 0.25 ms of the
+// kernel on C2.  Returns the number of entries emitted by all earlier chunks; every lane gets it.
+__device__ __forceinline__ unsigned long long rl_lookback(unsigned long long *__restrict__ status, uint32_t chunk,
+                                                          unsigned long long mine_count, bool *fail) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long *mine = status + chunk;
+  *fail = false;
+  if (chunk == 0) {
+    if (lane == 0) __hip_atomic_store(mine, kRsFlagIncl | mine_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  if (lane == 0) __hip_atomic_store(mine, kRsFlagAgg | mine_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long excl = 0;
+  int64_t top = (int64_t)chunk - 1;  // lane l looks at chunk top - l
+  const unsigned long long t0 = wall_clock64();
+  bool bad = false;
+  while (true) {
+    const int64_t t = top - lane;
+    unsigned long long w = kRsFlagIncl;  // before chunk 0: an inclusive prefix of nothing
+    if (t >= 0) w = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long f = w >> 62;
+    const uint64_t incl = __ballot(f == 2), pending = __ballot(f == 0), poison = __ballot(f == 3);
+    // the nearest inclusive prefix, and everything nearer than it, must be there
+    const int stop = incl ? __builtin_ctzll(incl) : 64;
+    const uint64_t nearer = stop >= 64 ? ~0ull : ((1ull << stop) - 1ull);
+    if (poison & (nearer | (stop < 64 ? (1ull << stop) : 0ull))) { bad = true; break; }
+    if (pending & nearer) {
+      if (wall_clock64() - t0 > kRsSpinLimit) { bad = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    unsigned long long v = (lane <= stop && lane < 64) ? (w & kRsValMask) : 0ull;
+    if (lane > stop) v = 0;
+    excl += wave_reduce(v, OpAdd());
+    if (stop < 64) break;
+    top -= 64;
+  }
+  *fail = bad;
+  if (lane == 0) {
+    if (bad) __hip_atomic_store(mine, kRsFlagPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(mine, kRsFlagIncl | (excl + mine_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return excl;
+}
+
+template <class T, class I, bool INDIRECT, int ITEMS, int DB>
+__global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
+    const uint64_t *__restrict__ kin, const typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *__restrict__ pin,
+    const T *__restrict__ vals_src, const uint32_t *__restrict__ chunk_a, uint32_t nchunks, int tb, int minor_bits,
+    I *__restrict__ col_out, T *__restrict__ vals_out, int64_t *__restrict__ row_ptr, int row_atomic,
+    unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket, unsigned long long *__restrict__ merged_out,
+    int *__restrict__ oversize, int *__restrict__ err, int lab) {
+  typedef typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type P;
+  constexpr int CAP = kBlock * ITEMS;
+  static_assert(CAP <= (1 << kRlTagBits), "position tag too narrow");
+  constexpr int CAPP = CAP + CAP / 32 + 1;
+  constexpr int NBH = (1 << DB) / 2;
+  constexpr size_t kR1 = ((size_t)CAPP * 8 + 15) & ~(size_t)15;  // composites / counters / emitted columns
+  constexpr size_t kPV = sizeof(P) > sizeof(T) ? sizeof(P) : sizeof(T);
+  constexpr size_t kR2 = ((size_t)CAPP * kPV + 15) & ~(size_t)15;  // payloads by position / emitted values
+  static_assert((size_t)(NBH * kBlock + NBH * kBlock / 32 + 1) * 4 <= kR1, "counters do not fit the composite buffer");
+  __shared__ __align__(16) unsigned char raw[kR1 + kR2];
+  __shared__ uint32_t top_tab[kRlMaxBuckets];
+  __shared__ uint32_t shs[kWaves];
+  __shared__ uint32_t s_chunk;
+  __shared__ unsigned long long s_off;
+  __shared__ int s_fail;
+  uint64_t *scomp = reinterpret_cast<uint64_t *>(raw);
+  P *spay = reinterpret_cast<P *>(raw + kR1);
+  uint32_t *C = reinterpret_cast<uint32_t *>(raw);
+  I *scol = reinterpret_cast<I *>(raw);
+  T *sval = reinterpret_cast<T *>(raw + kR1);
+
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_chunk = atomicAdd(ticket, 1u);
+    s_fail = 0;
+  }
+  __syncthreads();
+  const uint32_t chunk = s_chunk;
+  if (chunk >= nchunks) return;
+  const uint32_t a = chunk_a[chunk], b = chunk_a[chunk + 1];
+  const uint32_t L = b - a;
+  const bool last_chunk = chunk + 1 == nchunks;
+  if (L == 0 || L > (uint32_t)CAP) {  // nothing here, or it does not fit: pass the count on, say so
+    if (tid < 64) {
+      bool fail;
+      const unsigned long long off = rl_lookback(status, chunk, 0, &fail);
+      if (tid == 0) {
+        if (L) *oversize = 1;
+        if (fail) *err = 1;
+        else if (last_chunk) *merged_out = off;
+      }
+    }
+    return;
+  }
+  const int R = (int)((L + kBlock - 1) / kBlock);
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const uint32_t i = (uint32_t)k * kBlock + tid;
+    if (k < R && i < L) {
+      scomp[rl_pad(i)] = kin[a + i];
+      spay[rl_pad(i)] = pin[a + i];
+    }
+  }
+  __syncthreads();
+  uint64_t comp[ITEMS];
+  uint32_t rank[ITEMS];
+  const uint32_t pbase = (uint32_t)tid * (uint32_t)R;
+  const int lowbits = tb;  // begin_bit = 0
+  const uint64_t lowmask = (1ull << lowbits) - 1ull;
+  uint32_t heads = 0;
+  {
+    uint64_t before = (pbase > 0 && pbase < L) ? scomp[rl_pad(pbase - 1)] : 0ull;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const uint32_t p = pbase + k;
+      const bool live = k < R && p < L;
+      comp[k] = live ? scomp[rl_pad(p)] : ~0ull;  // still the key
+      const bool head = live && (p == 0 || (comp[k] >> tb) != (before >> tb));
+      heads += head ? 1u : 0u;
+      rank[k] = head ? (heads | 0x80000000u) : heads;  // inclusive count in the thread, top bit = bucket head
+      before = comp[k];
+    }
+  }
+  uint32_t nbk;
+  const uint32_t hex = block_exclusive_add<uint32_t>(heads, shs, nbk);  // ends with a barrier: every key is in registers
+  if (nbk > (uint32_t)kRlMaxBuckets) {
+    if (tid < 64) {
+      bool fail;
+      const unsigned long long off = rl_lookback(status, chunk, 0, &fail);
+      if (tid == 0) {
+        *oversize = 1;
+        if (fail) *err = 1;
+        else if (last_chunk) *merged_out = off;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const uint32_t p = pbase + k;
+    if (k < R && p < L) {
+      const uint32_t o = hex + (rank[k] & 0x7fffffffu) - 1u;
+      if (rank[k] & 0x80000000u) top_tab[o] = (uint32_t)(comp[k] >> tb);
+      comp[k] = ((((uint64_t)o << lowbits) | (comp[k] & lowmask)) << kRlTagBits) | p;
+    }
+  }
+  const int ordbits = nbk > 1 ? 32 - __builtin_clz(nbk - 1) : 0;
+  int passes = (lowbits + ordbits + DB - 1) / DB;
+  if ((lab & 0xff) > 0 && passes > (lab & 0xff) - 1) passes = (lab & 0xff) - 1;  // lab: at most this many passes (wrong result)
+  for (int pass = 0; pass < passes; pass++) {
+    const int shift = kRlTagBits + DB * pass;
+#pragma unroll
+    for (int j = 0; j < NBH; j++) C[rl_pad((uint32_t)j * kBlock + tid)] = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      if (k < R) {
+        const uint32_t d = (uint32_t)(comp[k] >> shift) & (uint32_t)((1 << DB) - 1);
+        const uint32_t old = atomicAdd(&C[rl_pad((d & (NBH - 1)) * kBlock + tid)], d >= NBH ? 65536u : 1u);
+        rank[k] = d >= NBH ? old >> 16 : old & 0xffffu;
+      }
+    }
+    __syncthreads();
+    {
+      uint32_t w[NBH], sum = 0;
+#pragma unroll
+      for (int q = 0; q < NBH; q++) {
+        w[q] = C[rl_pad((uint32_t)tid * NBH + q)];
+        sum += w[q];
+      }
+      uint32_t total;
+      uint32_t run = block_exclusive_add<uint32_t>(sum, shs, total);
+      run += total << 16;
+#pragma unroll
+      for (int q = 0; q < NBH; q++) {
+        C[rl_pad((uint32_t)tid * NBH + q)] = run;
+        run += w[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      if (k < R) {
+        const uint32_t d = (uint32_t)(comp[k] >> shift) & (uint32_t)((1 << DB) - 1);
+        const uint32_t word = C[rl_pad((d & (NBH - 1)) * kBlock + tid)];
+        rank[k] += d >= NBH ? word >> 16 : word & 0xffffu;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+      if (k < R) scomp[rl_pad(rank[k])] = comp[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++)
+      if (k < R) comp[k] = scomp[rl_pad(pbase + k)];
+    if (pass + 1 < passes) __syncthreads();  // the next pass's counters overwrite the buffer
+  }
+  // ---- emission.  scomp holds the sorted composites (dead ones, all ones, behind the L live ones); thread t has
+  // those of positions pbase .. pbase + R - 1 in registers.
+  uint32_t hc = 0, headmask = 0;
+  {
+    uint64_t prev_id = (pbase > 0 && pbase <= L) ? (scomp[rl_pad(pbase - 1)] >> kRlTagBits) : 0ull;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const uint32_t p = pbase + k;
+      const bool live = k < R && p < L;
+      const uint64_t id = comp[k] >> kRlTagBits;
+      const bool head = live && (p == 0 || id != prev_id);
+      prev_id = id;
+      hc += head ? 1u : 0u;
+      headmask |= head ? (1u << k) : 0u;
+      rank[k] = hc;  // inclusive count of run heads in the thread
+    }
+  }
+  uint32_t U;
+  const uint32_t uex = block_exclusive_add<uint32_t>(hc, shs, U);
+  if (tid < 64) {  // wave 0: the chunk's first output slot; the other waves fold their runs meanwhile
+    bool fail = false;
+    const unsigned long long off = (lab & 0x400) ? (unsigned long long)a : rl_lookback(status, chunk, U, &fail);
+    if (tid == 0) {
+      if (fail) {
+        *err = 1;
+        s_fail = 1;
+      }
+      s_off = off;
+      if (!fail && last_chunk) *merged_out = off + U;
+    }
+  }
+  I ocol[ITEMS];
+  T oval[ITEMS];
+  uint32_t endmask = 0;
+  uint64_t orow[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const uint32_t p = pbase + k;
+    ocol[k] = 0;
+    oval[k] = (T)0;
+    orow[k] = 0;
+    if (k < R && p < L) {
+      const uint64_t id = comp[k] >> kRlTagBits;
+      const uint64_t key = ((uint64_t)top_tab[(uint32_t)(id >> lowbits)] << tb) | (id & lowmask);
+      if ((headmask & (1u << k)) && !(lab & 0x800)) {
+        auto value_at = [&](uint64_t c) -> T {
+          const P pv = spay[rl_pad((uint32_t)c & ((1u << kRlTagBits) - 1u))];
+          if constexpr (INDIRECT) return vals_src[pv];
+          else return rl_from_bits<T>(pv);
+        };
+        T acc = value_at(comp[k]);
+        for (uint32_t j = p + 1; j < L; j++) {  // the rest of the run, in input order (the sort is stable)
+          const uint64_t cj = scomp[rl_pad(j)];
+          if ((cj >> kRlTagBits) != id) break;
+          acc = (T)(acc + value_at(cj));
+        }
+        ocol[k] = (I)(key & ((minor_bits >= 64) ? ~0ull : ((1ull << minor_bits) - 1ull)));
+        oval[k] = acc;
+      }
+      // last pair of its row inside the chunk?
+      bool rend = p + 1 >= L;
+      if (!rend) {
+        const uint64_t nid = scomp[rl_pad(p + 1)] >> kRlTagBits;
+        const uint64_t nkey = ((uint64_t)top_tab[(uint32_t)(nid >> lowbits)] << tb) | (nid & lowmask);
+        rend = (minor_bits >= 64 ? 0ull : (nkey >> minor_bits)) != (minor_bits >= 64 ? 0ull : (key >> minor_bits));
+      }
+      if (rend && !(lab & 0x200)) {
+        endmask |= 1u << k;
+        orow[k] = minor_bits >= 64 ? 0ull : (key >> minor_bits);
+      }
+    }
+  }
+  __syncthreads();  // composites and payloads are spent; s_off is there
+  if (s_fail) return;
+  const unsigned long long off = s_off;
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    if (k < R) {
+      const uint32_t slot = uex + rank[k];  // inclusive: runs up to and including this pair's
+      if (headmask & (1u << k)) {
+        scol[slot - 1] = ocol[k];
+        sval[slot - 1] = oval[k];
+      }
+      if (endmask & (1u << k)) {
+        const int64_t v = (int64_t)(off + slot);
+        if (row_atomic) atomicMax(reinterpret_cast<unsigned long long *>(row_ptr + orow[k] + 1), (unsigned long long)v);
+        else row_ptr[orow[k] + 1] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (lab & 0x100) return;
+  for (uint32_t u = tid; u < U; u += kBlock) {
+    col_out[off + u] = scol[u];
+    vals_out[off + u] = sval[u];
+  }
+}
+
 // Sorts like radix_sort_pairs, bits [begin_bit, end_bit), with the bits from tb up by global passes and the rest
 // per chunk.  *oversize (device int, zeroed by the caller) is raised if a chunk did not fit.
 template <class K, class P>
@@ -361,6 +685,46 @@ int radix_sort_pairs_msd(futhark_context *ctx, K *keys_a, K *keys_b, const P *pa
   SAMD_LAUNCH_CHECK(ctx);
   *keys_out = kfree;
   *pay_out = pfree;
+  return 0;
+}
+
+// Assembly through the fused kernel: global passes on key bits [tb, end_bit), then one launch that sorts the rest
+// per chunk and writes the record.  col_out / vals_out hold n slots; *merged_out (device) receives the number of
+// stored entries; row_ptr (zeroed by the caller) receives the row ends (the caller's max-scan fills empty rows).
+template <class T>
+struct RlEmitCfg {
+  static constexpr int kItems = sizeof(T) > 4 ? 16 : 20;
+  static constexpr int kCap = kBlock * kItems;
+};
+
+template <class T, class I, bool INDIRECT>
+int msd_sort_emit(futhark_context *ctx, uint64_t *keys_a, uint64_t *keys_b,
+                  const typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *pay_in,
+                  typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *pay_a,
+                  typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *pay_b,
+                  const T *vals_src, int64_t n, int tb, int end_bit, uint32_t ch, int minor_bits, I *col_out, T *vals_out,
+                  int64_t *row_ptr, unsigned long long *merged_out, int *sort_err, int *oversize) {
+  typedef typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type P;
+  uint64_t *ks = nullptr;
+  const P *ps = nullptr;
+  SAMD_TRY((radix_sort_pairs<uint64_t, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, tb, end_bit, &ks, &ps, sort_err)));
+  if (ps == nullptr || ps == pay_in) return set_error(ctx, "internal: msd sort without a global pass");
+  const uint32_t nchunks = (uint32_t)cdiv(n, (int64_t)ch);
+  Tmp<uint32_t> ca(ctx);
+  Tmp<unsigned long long> status(ctx);
+  SAMD_TRY(ca.get((int64_t)nchunks + 2));
+  SAMD_TRY(status.get(nchunks));
+  uint32_t *ticket = ca.p + nchunks + 1;
+  SAMD_HIP(ctx, hipMemsetAsync(ticket, 0, sizeof(uint32_t), ctx->stream));
+  SAMD_HIP(ctx, hipMemsetAsync(status.p, 0, sizeof(unsigned long long) * (size_t)nchunks, ctx->stream));
+  hipLaunchKernelGGL((msd_chunk_plan_kernel<uint64_t>), dim3((unsigned)cdiv((int64_t)nchunks + 1, kBlock)), dim3(kBlock), 0,
+                     ctx->stream, (const uint64_t *)ks, (uint32_t)n, tb, ch, nchunks, ca.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL((rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItems, kRlDigitBits>), dim3(nchunks), dim3(kBlock),
+                     0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)ca.p, nchunks, tb, minor_bits,
+                     col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0, status.p, ticket, merged_out, oversize, sort_err,
+                     (int)ctx->opt_ablate);
+  SAMD_LAUNCH_CHECK(ctx);
   return 0;
 }
 
