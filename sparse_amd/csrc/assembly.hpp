@@ -222,15 +222,28 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     typedef typename BitsOf<T>::type VB;
     bool indirect = sizeof(T) > 4;
     if (sizeof(T) > 4 && ctx->opt_sort_indirect < 0) indirect = false;
-    if (sizeof(T) > 4 && ctx->opt_sort_indirect == 0 && count >= (1 << 20) && end_bit - begin_bit > 16) {
-      SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+    const bool sample_far = sizeof(T) > 4 && ctx->opt_sort_indirect == 0 && count >= (1 << 20) && end_bit - begin_bit > 16;
+    if (sample_far) {
+      SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 8, 0, sizeof(int64_t), ctx->stream));
       const double keyspace = ldexp((double)(n_major > 0 ? n_major : 1), minor_bits);
       const unsigned long long cap = (unsigned long long)count;
       hipLaunchKernelGGL((displacement_sample_kernel<K>), dim3(16), dim3(kBlock), 0, ctx->stream, (const K *)keys.p,
-                         count, 1.0 / keyspace, cap, reinterpret_cast<unsigned long long *>(ctx->d_small));
+                         count, 1.0 / keyspace, cap, reinterpret_cast<unsigned long long *>(ctx->d_small + 8));
       SAMD_LAUNCH_CHECK(ctx);
-      int64_t far = 0;
-      SAMD_TRY(read_small(ctx, ctx->d_small, 1, &far));
+    }
+    // fewer trips through HBM when the key's top bits cut the input into small even buckets (radix_sort_msd.hpp):
+    // top bits by global passes, then one kernel that sorts the rest inside LDS and writes the record itself.
+    // Its sample and the one above share one read-back.
+    int msd_tb = -1;
+    uint32_t msd_ch = 0;
+    int64_t far = -1;
+    if constexpr (sizeof(K) == 8) {
+      if (allow_msd && begin_bit == 0 && end_bit <= 64 - kRlTagBits)
+        SAMD_TRY(msd_choose<K>(ctx, keys.p, count, begin_bit, end_bit, RlEmitCfg<T>::kCap, &msd_tb, &msd_ch, &far));
+      if (msd_tb > 40) msd_tb = -1;  // composite = ordinal (<= 11 bits) | low bits | 13-bit tag
+    }
+    if (sample_far) {
+      if (far < 0) SAMD_TRY(read_small(ctx, ctx->d_small + 8, 1, &far));
       const double mean = (double)far / (16.0 * kBlock);
       indirect = mean * sizeof(T) <= (double)(1 << 20);
     }
@@ -242,15 +255,6 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     K *ks = nullptr;
     const uint32_t *perm = nullptr;
     const T *vs = nullptr;
-    // fewer trips through HBM when the key's top bits cut the input into small even buckets (radix_sort_msd.hpp):
-    // top bits by global passes, then one kernel that sorts the rest inside LDS and writes the record itself
-    int msd_tb = -1;
-    uint32_t msd_ch = 0;
-    if constexpr (sizeof(K) == 8) {
-      if (allow_msd && begin_bit == 0 && end_bit <= 64 - kRlTagBits)
-        SAMD_TRY(msd_choose<K>(ctx, keys.p, count, begin_bit, end_bit, RlEmitCfg<T>::kCap, &msd_tb, &msd_ch));
-      if (msd_tb > 40) msd_tb = -1;  // composite = ordinal (<= 11 bits) | low bits | 13-bit tag
-    }
     ctx->last_sort_msd = msd_tb >= 0 ? end_bit - msd_tb : 0;
     SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 2, 0, 2 * sizeof(int64_t), ctx->stream));
     int *sort_err = (int *)(ctx->d_small + 2), *oversize = (int *)(ctx->d_small + 3);

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void msd_max_kernel(const uint32_t *__restr
 // nominal chunk length.  One small read-back.
 template <class K>
 int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit, int end_bit, int cap, int *tb,
-               uint32_t *ch) {
+               uint32_t *ch, int64_t *slot8 = nullptr) {  // slot8: receives d_small[8] if this call reads back (else untouched)
   *tb = -1;
   *ch = 0;
   const int total = end_bit - begin_bit;
@@ -133,8 +133,9 @@ int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit
     hipLaunchKernelGGL(msd_max_kernel, dim3(64), dim3(kBlock), 0, ctx->stream, (const uint32_t *)hist.p, res);
     SAMD_LAUNCH_CHECK(ctx);
   }
-  int64_t h[4];
-  SAMD_TRY(read_small(ctx, ctx->d_small + 4, 4, h));
+  int64_t h[5];
+  SAMD_TRY(read_small(ctx, ctx->d_small + 4, 5, h));
+  if (slot8) *slot8 = h[4];
   if (msd_gate_skewed((unsigned long long)h[2], (unsigned long long)h[3]) || h[1] <= 0) return 0;  // skewed at first sight
   const double per_sample = (double)count / (double)samples;
   const double max16 = (double)h[0] * per_sample;            // largest 16-bit bucket, estimated (from above)
