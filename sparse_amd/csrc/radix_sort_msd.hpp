@@ -1,17 +1,18 @@
-// radix_sort_msd.hpp -- the same stable sort with fewer trips through HBM: the TOP key bits by global passes,
-// everything below them inside LDS.
+// radix_sort_msd.hpp -- assembly with fewer trips through HBM: the TOP key bits by global passes, everything
+// below them inside LDS, and the record written straight from there.
 //
 // An LSD sort of b key bits moves every pair through HBM b/8 times (C2: 48 bits, six passes, 5.5 of the
-// assembly's 7.5 ms).  Here the top T bits (16 or 24) are sorted first by the ordinary stable passes of
-// radix_sort.hpp, which leaves the pairs grouped into 2^T buckets, input order kept inside each bucket.  When the
-// buckets are small, one more kernel finishes the job: a workgroup takes a chunk of whole consecutive buckets
-// (<= kCap pairs), sorts it by the remaining low bits with in-LDS passes and then, stably, by the ordinal of the
-// bucket inside the chunk, and writes it back in place.  Two or three global passes plus one read and one write.
+// assembly's 7.5 ms), and head-flag scan + merge_emit read the sorted pairs twice more.  Here the top T bits (16 or
+// 24) are sorted first by the ordinary stable passes of radix_sort.hpp, which leaves the pairs grouped into 2^T
+// buckets, input order kept inside each bucket.  When the buckets are small, one more kernel finishes the job: a
+// workgroup takes a chunk of whole consecutive buckets, sorts it by the remaining low bits inside LDS, folds the
+// duplicates and writes col_idx / vals / row ends (rs_local_sort_emit).  Two or three global passes plus one read
+// of the pairs and one write of the record.  Measured: C2 7.5 -> 5.3 ms, C5 85 -> 65 ms, C4 2.25 -> 2.0 ms.
 //
 // Which T, if any, is decided from a sampled histogram of the top 16 bits (msd_choose): skewed keys (power-law
-// rows) keep the LSD sort.  The estimate can be wrong; a chunk that does not fit its workgroup is copied through
-// unsorted and raises *oversize, which the caller reads at its next synchronisation and answers by sorting
-// again without this file (assembly.hpp).
+// rows, C3) keep the LSD sort.  The estimate can be wrong; a chunk that does not fit its workgroup emits nothing and
+// raises *oversize, which the caller reads at its one synchronisation and answers by assembling again without
+// this file (assembly.hpp: kAssembleAgain).
 #pragma once
 
 #include <type_traits>
@@ -30,14 +31,6 @@ __device__ __forceinline__ T rl_from_bits(typename RlBits<T>::type v) {
   __builtin_memcpy(&out, &v, sizeof(T));
   return out;
 }
-
-template <class K, class P>
-struct RlCfg {
-  // items per thread: key + payload + 2-byte bucket ordinal per pair in LDS, two workgroups per CU (<= 78 KB each)
-  static constexpr int kPair = (int)(sizeof(K) + sizeof(P));
-  static constexpr int kItems = kPair <= 8 ? 28 : (kPair <= 12 ? 20 : 16);
-  static constexpr int kCap = kBlock * kItems;
-};
 
 constexpr int kRlDigitBits = 5;  // in-LDS passes: 32 digits, 16 counter words per thread (6 bits: one pass fewer on C2, same time)
 constexpr int kMsdBins = 1 << 16;
@@ -189,168 +182,9 @@ __global__ __launch_bounds__(kBlock) void msd_chunk_plan_kernel(const K *__restr
   a[c] = (uint32_t)t;
 }
 
-// One chunk per workgroup: stable sort by key bits [begin_bit, tb) inside every bucket (= run of equal bits
-// >= tb) of the chunk, i.e. by the composite (ordinal of the bucket in the chunk, low key bits).
-//
-// Pairs live in registers in the BLOCKED arrangement (thread t holds positions t*R .. t*R+R-1, R = rounds the
-// chunk needs), and a pass of DB bits ranks them with thread-private counters: counter (digit, thread) counts the
-// thread's pairs of that digit (one LDS add-with-return per pair, no dependent chain and no ballots), a block-wide
-// scan in (digit, thread) order turns the counters into bases, rank = base + pairs of the same digit earlier in
-// the same thread: stable.  Two 16-bit counters share a word (digits d and d + 2^DB/2), so one scan serves both
-// halves (the upper half gets the lower half's total added).  A ballot-based match-any ranking (as in the global
-// passes) was the first version: 8 ballots and ~60 vector instructions per pair and pass made the kernel
-// compute-bound at 2.2 ms on C2; this one needs ~10.
-// The counters alias the pair buffer: pairs are in registers while counters are live.
-// Addresses are padded by one slot per 32 so that the blocked reads (lane stride R) stay off each other's banks.
+// Addresses are padded by one slot per 32 so that blocked reads (lane stride = items per thread) stay off each
+// other's banks.
 __device__ __forceinline__ uint32_t rl_pad(uint32_t i) { return i + (i >> 5); }
-
-template <class K, class P, int ITEMS, int DB>
-__global__ __launch_bounds__(kBlock) void rs_local_sort(const K *__restrict__ kin, const P *__restrict__ pin,
-                                                        K *__restrict__ kout, P *__restrict__ pout,
-                                                        const uint32_t *__restrict__ chunk_a, int begin_bit, int tb,
-                                                        int *__restrict__ oversize, int lab) {
-  constexpr int CAP = kBlock * ITEMS;
-  constexpr int CAPP = CAP + CAP / 32 + 1;
-  constexpr int NBH = (1 << DB) / 2;                 // counter words per thread (two digits each)
-  constexpr int CW = NBH * kBlock + NBH * kBlock / 32 + 1;
-  constexpr size_t kDataBytes = (size_t)CAPP * (sizeof(K) + sizeof(P) + 2) + 32;
-  constexpr size_t kCntBytes = (size_t)CW * 4;
-  constexpr size_t kRaw = kDataBytes > kCntBytes ? kDataBytes : kCntBytes;
-  __shared__ __align__(16) unsigned char raw[kRaw];
-  __shared__ uint32_t shs[kWaves];
-  K *skey = reinterpret_cast<K *>(raw);
-  P *spay = reinterpret_cast<P *>(raw + (((size_t)CAPP * sizeof(K) + 15) & ~(size_t)15));
-  uint16_t *sord = reinterpret_cast<uint16_t *>(raw + (((size_t)CAPP * sizeof(K) + 15) & ~(size_t)15) +
-                                                (((size_t)CAPP * sizeof(P) + 15) & ~(size_t)15));
-  uint32_t *C = reinterpret_cast<uint32_t *>(raw);
-
-  const int tid = threadIdx.x;
-  const uint32_t a = chunk_a[blockIdx.x], b = chunk_a[blockIdx.x + 1];
-  const uint32_t L = b - a;
-  if (L == 0) return;
-  if (L > (uint32_t)CAP) {  // does not fit: leave the pairs as they are (valid keys, wrong order) and say so
-    if (tid == 0) *oversize = 1;
-    for (uint32_t i = a + tid; i < b; i += kBlock) {
-      kout[i] = kin[i];
-      pout[i] = pin[i];
-    }
-    return;
-  }
-  // coalesced load into LDS, then every thread takes its R consecutive pairs
-  const int R = (int)((L + kBlock - 1) / kBlock);
-#pragma unroll
-  for (int k = 0; k < ITEMS; k++) {
-    const uint32_t i = (uint32_t)k * kBlock + tid;
-    if (k < R && i < L) {
-      skey[rl_pad(i)] = kin[a + i];
-      spay[rl_pad(i)] = pin[a + i];
-    }
-  }
-  __syncthreads();
-  K key[ITEMS];
-  P pay[ITEMS];
-  uint32_t ord[ITEMS], prev[ITEMS];
-  const uint32_t pbase = (uint32_t)tid * (uint32_t)R;
-  uint32_t heads = 0;
-  {
-    K before = (pbase > 0 && pbase < L) ? skey[rl_pad(pbase - 1)] : (K)0;
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      const uint32_t p = pbase + k;
-      const bool live = k < R && p < L;
-      key[k] = live ? skey[rl_pad(p)] : (K)~(K)0;
-      pay[k] = live ? spay[rl_pad(p)] : (P)0;
-      const bool head = live && (p == 0 || (K)(key[k] >> tb) != (K)(before >> tb));
-      heads += head ? 1u : 0u;
-      ord[k] = heads;  // inclusive count inside the thread
-      before = key[k];
-    }
-  }
-  uint32_t nbk;
-  {
-    const uint32_t ex = block_exclusive_add<uint32_t>(heads, shs, nbk);  // ends with a barrier: the buffer is free
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) ord[k] = (k < R && pbase + k < L) ? ex + ord[k] - 1u : 0xffffffffu;
-  }
-  const int lowbits = tb - begin_bit;
-  const int ordbits = nbk > 1 ? 32 - __builtin_clz(nbk - 1) : 0;
-  int passes = (lowbits + ordbits + DB - 1) / DB;
-  if (lab > 0 && passes > lab - 1) passes = lab - 1;  // lab: at most lab - 1 passes (the result is then wrong)
-  const uint64_t lowmask = lowbits >= 64 ? ~0ull : ((1ull << lowbits) - 1ull);
-  for (int pass = 0; pass < passes; pass++) {
-    const int shift = DB * pass;
-    uint32_t dg[ITEMS];
-    // this thread's column of counters: zero, then count (same thread, LDS keeps its order)
-#pragma unroll
-    for (int j = 0; j < NBH; j++) C[rl_pad((uint32_t)j * kBlock + tid)] = 0;
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      if (k < R) {
-        const uint64_t comp = ((uint64_t)ord[k] << lowbits) | ((uint64_t)(key[k] >> begin_bit) & lowmask);
-        const uint32_t d = (uint32_t)(comp >> shift) & (uint32_t)((1 << DB) - 1);
-        dg[k] = d;
-        const uint32_t old = atomicAdd(&C[rl_pad((d & (NBH - 1)) * kBlock + tid)], d >= NBH ? 65536u : 1u);
-        prev[k] = d >= NBH ? old >> 16 : old & 0xffffu;
-      }
-    }
-    __syncthreads();
-    // scan in (digit, thread) order: thread s owns the NBH consecutive words from s * NBH
-    {
-      uint32_t w[NBH], sum = 0;
-#pragma unroll
-      for (int q = 0; q < NBH; q++) {
-        w[q] = C[rl_pad((uint32_t)tid * NBH + q)];
-        sum += w[q];
-      }
-      uint32_t total;
-      uint32_t run = block_exclusive_add<uint32_t>(sum, shs, total);
-      run += total << 16;  // digits of the upper halves come after all digits of the lower halves
-#pragma unroll
-      for (int q = 0; q < NBH; q++) {
-        C[rl_pad((uint32_t)tid * NBH + q)] = run;
-        run += w[q];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      if (k < R) {
-        const uint32_t d = dg[k];
-        const uint32_t word = C[rl_pad((d & (NBH - 1)) * kBlock + tid)];
-        prev[k] += d >= NBH ? word >> 16 : word & 0xffffu;  // = rank
-      }
-    }
-    __syncthreads();  // counters are spent: the buffer takes the pairs
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      if (k < R) {
-        const uint32_t q = rl_pad(prev[k]);
-        skey[q] = key[k];
-        spay[q] = pay[k];
-        sord[q] = (uint16_t)ord[k];
-      }
-    }
-    __syncthreads();
-    if (pass + 1 < passes) {
-#pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        if (k < R) {
-          const uint32_t q = rl_pad(pbase + k);
-          key[k] = skey[q];
-          pay[k] = spay[q];
-          const uint32_t o = sord[q];
-          ord[k] = o == 0xffffu ? 0xffffffffu : o;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // dead pairs (all-ones keys and ordinals) ended up behind the L live ones
-  for (uint32_t i = tid; i < L; i += kBlock) {
-    kout[a + i] = skey[rl_pad(i)];
-    pout[a + i] = spay[rl_pad(i)];
-  }
-}
 
 // ------------------------------------------------------------------ in-LDS sort fused with the record's emission
 // The assembly's own version of the kernel above (assembly.hpp calls it; begin_bit = 0): the chunk is sorted as
@@ -660,33 +494,6 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
     col_out[off + u] = scol[u];
     vals_out[off + u] = sval[u];
   }
-}
-
-// Sorts like radix_sort_pairs, bits [begin_bit, end_bit), with the bits from tb up by global passes and the rest
-// per chunk.  *oversize (device int, zeroed by the caller) is raised if a chunk did not fit.
-template <class K, class P>
-int radix_sort_pairs_msd(futhark_context *ctx, K *keys_a, K *keys_b, const P *pay_in, P *pay_a, P *pay_b, int64_t n,
-                         int begin_bit, int tb, int end_bit, uint32_t ch, K **keys_out, const P **pay_out,
-                         int *sort_err, int *oversize) {
-  constexpr int ITEMS = RlCfg<K, P>::kItems;
-  K *ks = nullptr;
-  const P *ps = nullptr;
-  SAMD_TRY((radix_sort_pairs<K, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, tb, end_bit, &ks, &ps, sort_err)));
-  if (ps == nullptr || ps == pay_in) return set_error(ctx, "internal: msd sort without a global pass");
-  K *kfree = ks == keys_a ? keys_b : keys_a;
-  P *pfree = ps == pay_a ? pay_b : pay_a;
-  const uint32_t nchunks = (uint32_t)cdiv(n, (int64_t)ch);
-  Tmp<uint32_t> ca(ctx);
-  SAMD_TRY(ca.get((int64_t)nchunks + 1));
-  hipLaunchKernelGGL((msd_chunk_plan_kernel<K>), dim3((unsigned)cdiv((int64_t)nchunks + 1, kBlock)), dim3(kBlock), 0,
-                     ctx->stream, (const K *)ks, (uint32_t)n, tb, ch, nchunks, ca.p);
-  SAMD_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL((rs_local_sort<K, P, ITEMS, kRlDigitBits>), dim3(nchunks), dim3(kBlock), 0, ctx->stream, (const K *)ks, ps, kfree,
-                     pfree, (const uint32_t *)ca.p, begin_bit, tb, oversize, (int)ctx->opt_ablate);
-  SAMD_LAUNCH_CHECK(ctx);
-  *keys_out = kfree;
-  *pay_out = pfree;
-  return 0;
 }
 
 // Assembly through the fused kernel: global passes on key bits [tb, end_bit), then one launch that sorts the rest

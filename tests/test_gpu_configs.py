@@ -143,7 +143,7 @@ def test_c5_random_1e9_f64_whole_record_on_one_gpu(env):
     y = torch.as_tensor(M.sr.smvm(A, x), device=dev).clone()
     assert ctx.get_option("spmv_last_path") == 3, "the two-pass path was not chosen"
     y_again = torch.as_tensor(M.sr.smvm(A, x), device=dev)      # reproducible up to the order of the LDS atomics
-    assert float(((y_again - y).abs() / y.abs()).max()) <= 1e-15
+    assert float(((y_again - y).abs() / y.abs()).max()) <= 1e-13    # ~100 terms per row, a few ulp of reordering
     del y_again
     # row_off against torch's histogram of the same row ids (duplicates counted once: compare the totals
     # and monotonicity, then the exact histogram on the rows of the merged record)

@@ -148,7 +148,7 @@ def test_c5_row_shard_two_pass_and_column_blocks_against_the_plain_kernel():
     y = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0").clone()
     assert ctx.get_option("spmv_last_path") == 3, "the two-pass path was not chosen"
     y_again = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0")
-    assert float(((y - y_again).abs() / y.abs()).max()) <= 1e-15
+    assert float(((y - y_again).abs() / y.abs()).max()) <= 1e-13   # ~100 terms per row, a few ulp of reordering
     del A
     ctx.set_option("spmv_pb", -1)
     try:

@@ -170,6 +170,11 @@ def test_sparse_top_bits_by_global_passes_rest_in_lds(ctx, dtype, indirect, top,
         r2, c2 = r.copy(), c.copy()
         r2[1000:4000], c2[1000:4000] = 77, 5
         assert_same_record(M.sr.sparse(n, m, (r2, c2, v)), O.sr_sparse(n, m, r2, c2, v))
+        # ten triples per coordinate: the count-sized output arrays are cut down to the merged length
+        r4, c4 = r % 173, (c % 173) * 577
+        A4 = M.sr.sparse(n, m, (r4, c4, v))
+        assert_same_record(A4, O.sr_sparse(n, m, r4, c4, v))
+        assert A4.stored_dims()[2] <= 173 * 173
         # a column range past int32: 50 key bits
         n3, m3 = 1 << 17, 1 << 33
         c3 = (synth.splitmix64(6, np.arange(k, dtype=np.uint64)) % np.uint64(m3)).astype(np.int64)
