@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--pb", type=int, default=0, help="spmv_pb option: -1 never, 1 also records of flat popularity, 2 always")
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="any context option, key=value (kernel lab)")
+    ap.add_argument("--asm-only", action="store_true", help="time the assembly only (kernel labs whose ablations leave a wrong record)")
     ap.add_argument("--compare", action="store_true", help="also time torch.sparse (rocSPARSE) CSR SpMV as a comparator")
     args = ap.parse_args()
     import torch
@@ -85,6 +86,12 @@ def main():
                "assembly_ms": round(asm * 1e3, 3), "assembly_first_ms": round(asm_first * 1e3, 3),
                "assembly_Mtriples_s": round(nnz0 / asm / 1e6, 1),
                "assembly_GBs": round((nnz0 * (16 + vb) + nnz * (4 + vb) + n * 8) / asm / 1e9, 1)}
+        if args.asm_only:
+            print(json.dumps(out), flush=True)
+            del A, r, c, v
+            ctx.clear_caches()
+            torch.cuda.empty_cache()
+            return
         if args.check:
             ref = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, m)).coalesce()
             ro, ci, va = A.fields()

@@ -236,10 +236,12 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     // Its sample and the one above share one read-back.
     int msd_tb = -1;
     uint32_t msd_ch = 0;
+    bool msd_small = false;
     int64_t far = -1;
     if constexpr (sizeof(K) == 8) {
       if (allow_msd && begin_bit == 0 && end_bit <= 64 - kRlTagBits)
-        SAMD_TRY(msd_choose<K>(ctx, keys.p, count, begin_bit, end_bit, RlEmitCfg<T>::kCap, &msd_tb, &msd_ch, &far));
+        SAMD_TRY(msd_choose<K>(ctx, keys.p, count, begin_bit, end_bit, RlEmitCfg<T>::kCap, RlEmitCfg<T>::kCapSmall, &msd_tb,
+                               &msd_ch, &msd_small, &far));
       if (msd_tb > 40) msd_tb = -1;  // composite = ordinal (<= 11 bits) | low bits | 13-bit tag
     }
     if (sample_far) {
@@ -271,11 +273,11 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
           SAMD_TRY(pay_b.get(count));
           if (c32)
             SAMD_TRY((msd_sort_emit<T, int32_t, true>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
-                                                       vals_in, count, msd_tb, end_bit, msd_ch, minor_bits, b->col32,
+                                                       vals_in, count, msd_tb, end_bit, msd_ch, msd_small, minor_bits, b->col32,
                                                        b->vals, b->row_ptr, merged_dev, sort_err, oversize)));
           else
             SAMD_TRY((msd_sort_emit<T, int64_t, true>(ctx, keys.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
-                                                       vals_in, count, msd_tb, end_bit, msd_ch, minor_bits, b->col64,
+                                                       vals_in, count, msd_tb, end_bit, msd_ch, msd_small, minor_bits, b->col64,
                                                        b->vals, b->row_ptr, merged_dev, sort_err, oversize)));
         } else {
           SAMD_TRY(val_a.get(count));
@@ -283,12 +285,12 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
           if (c32)
             SAMD_TRY((msd_sort_emit<T, int32_t, false>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in),
                                                         val_a.p, val_b.p, (const T *)nullptr, count, msd_tb, end_bit,
-                                                        msd_ch, minor_bits, b->col32, b->vals, b->row_ptr, merged_dev,
+                                                        msd_ch, msd_small, minor_bits, b->col32, b->vals, b->row_ptr, merged_dev,
                                                         sort_err, oversize)));
           else
             SAMD_TRY((msd_sort_emit<T, int64_t, false>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in),
                                                         val_a.p, val_b.p, (const T *)nullptr, count, msd_tb, end_bit,
-                                                        msd_ch, minor_bits, b->col64, b->vals, b->row_ptr, merged_dev,
+                                                        msd_ch, msd_small, minor_bits, b->col64, b->vals, b->row_ptr, merged_dev,
                                                         sort_err, oversize)));
         }
         if (err_flag)

@@ -84,10 +84,11 @@ __global__ __launch_bounds__(kBlock) void msd_max_kernel(const uint32_t *__restr
 // Chooses the number of top bits the global passes take (*tb = first of them; -1 = keep the LSD sort) and the
 // nominal chunk length.  One small read-back.
 template <class K>
-int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit, int end_bit, int cap, int *tb,
-               uint32_t *ch, int64_t *slot8 = nullptr) {  // slot8: receives d_small[8] if this call reads back (else untouched)
+int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit, int end_bit, int cap, int cap_small,
+               int *tb, uint32_t *ch, bool *small, int64_t *slot8 = nullptr) {  // slot8: receives d_small[8] if this call reads back
   *tb = -1;
   *ch = 0;
+  *small = false;
   const int total = end_bit - begin_bit;
   if (ctx->opt_sort_msd < 0 || count <= 0) return 0;
   if (ctx->opt_sort_msd > 0) {  // tests and labs: this many top bits, whatever the input
@@ -99,6 +100,7 @@ int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit
     uint32_t c = ctx->opt_sort_msd_chunk > 0 ? (uint32_t)ctx->opt_sort_msd_chunk : (uint32_t)cap / 2;
     if (c > (uint32_t)cap) c = (uint32_t)cap;
     *ch = c;
+    *small = ctx->opt_sort_msd_chunk > 0 && c <= (uint32_t)cap_small / 2;  // short chunks: the small-chunk kernel
     return 0;
   }
   if (count < kMsdMinCount || total <= 24 || end_bit < 16) return 0;
@@ -134,24 +136,24 @@ int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit
   const double max16 = (double)h[0] * per_sample;            // largest 16-bit bucket, estimated (from above)
   const double avg16 = (double)count / (double)h[1];
   if (max16 > 4.0 * avg16 + 64.0 * per_sample) return 0;     // skewed: the buckets below would not be even either
-  const double limit = 0.5 * cap;
-  double maxb;
-  int t;
-  if (max16 <= limit) {
-    t = 16;
-    maxb = max16;
-  } else {
+  // Fewest global passes first; within that, the smaller chunk (more workgroups per CU: C5 shard 3.0 -> 2.3 ms)
+  // if the buckets leave it at least half full.
+  double maxb = max16;
+  int t = 16;
+  if (maxb > 0.5 * cap) {
     // the next 8 bits split a bucket into up to 256; allow the finer level to be 4 times less even
     if (total <= 32) return 0;
     t = 24;
     maxb = max16 / 256.0 * 4.0 + 64.0;
-    if (maxb > limit) return 0;
+    if (maxb > 0.5 * cap) return 0;
   }
-  uint32_t c = (uint32_t)cap - (uint32_t)maxb;
+  const int use_cap = maxb <= 0.5 * cap_small ? cap_small : cap;
+  uint32_t c = (uint32_t)use_cap - (uint32_t)maxb;
   c &= ~255u;
-  if (c < (uint32_t)cap / 2) c = (uint32_t)cap / 2;
+  if (c < (uint32_t)use_cap / 2) c = (uint32_t)use_cap / 2;
   *tb = end_bit - t;
   *ch = c;
+  *small = use_cap == cap_small;
   return 0;
 }
 
@@ -196,7 +198,6 @@ __device__ __forceinline__ uint32_t rl_pad(uint32_t i) { return i + (i >> 5); }
 // workgroup writes col_idx / vals / row ends directly.  Replaces head-flag scan + merge_emit (C2: 0.95 ms) and the
 // 16-byte write + 20-byte read between them.
 constexpr int kRlTagBits = 13;
-constexpr int kRlMaxBuckets = 2048;   // bucket ordinals per chunk (top_tab); more = the chunk is refused like an oversize one
 
 // Look-back by one whole wavefront (all 64 lanes call it): 64 predecessors per step instead of one -- the first
 // 512 chunks of a launch start together and finish together, and a lane-by-lane walk over them was 0.25 ms of the
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
   constexpr size_t kR2 = ((size_t)CAPP * kPV + 15) & ~(size_t)15;  // payloads by position / emitted values
   static_assert((size_t)(NBH * kBlock + NBH * kBlock / 32 + 1) * 4 <= kR1, "counters do not fit the composite buffer");
   __shared__ __align__(16) unsigned char raw[kR1 + kR2];
+  constexpr int kRlMaxBuckets = CAP / 2;  // bucket ordinals per chunk; more = the chunk is refused like an oversize one
   __shared__ uint32_t top_tab[kRlMaxBuckets];
   __shared__ uint32_t shs[kWaves];
   __shared__ uint32_t s_chunk;
@@ -501,8 +503,11 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
 // stored entries; row_ptr (zeroed by the caller) receives the row ends (the caller's max-scan fills empty rows).
 template <class T>
 struct RlEmitCfg {
+  // two chunk sizes: 2 workgroups per CU for buckets of up to ~2000 pairs, 4 per CU when the buckets are small
   static constexpr int kItems = sizeof(T) > 4 ? 16 : 20;
   static constexpr int kCap = kBlock * kItems;
+  static constexpr int kItemsSmall = sizeof(T) > 4 ? 8 : 10;
+  static constexpr int kCapSmall = kBlock * kItemsSmall;
 };
 
 template <class T, class I, bool INDIRECT>
@@ -510,7 +515,7 @@ int msd_sort_emit(futhark_context *ctx, uint64_t *keys_a, uint64_t *keys_b,
                   const typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *pay_in,
                   typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *pay_a,
                   typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *pay_b,
-                  const T *vals_src, int64_t n, int tb, int end_bit, uint32_t ch, int minor_bits, I *col_out, T *vals_out,
+                  const T *vals_src, int64_t n, int tb, int end_bit, uint32_t ch, bool small, int minor_bits, I *col_out, T *vals_out,
                   int64_t *row_ptr, unsigned long long *merged_out, int *sort_err, int *oversize) {
   typedef typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type P;
   uint64_t *ks = nullptr;
@@ -528,10 +533,16 @@ int msd_sort_emit(futhark_context *ctx, uint64_t *keys_a, uint64_t *keys_b,
   hipLaunchKernelGGL((msd_chunk_plan_kernel<uint64_t>), dim3((unsigned)cdiv((int64_t)nchunks + 1, kBlock)), dim3(kBlock), 0,
                      ctx->stream, (const uint64_t *)ks, (uint32_t)n, tb, ch, nchunks, ca.p);
   SAMD_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL((rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItems, kRlDigitBits>), dim3(nchunks), dim3(kBlock),
-                     0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)ca.p, nchunks, tb, minor_bits,
-                     col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0, status.p, ticket, merged_out, oversize, sort_err,
-                     (int)ctx->opt_ablate);
+  if (small)
+    hipLaunchKernelGGL((rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItemsSmall, kRlDigitBits>), dim3(nchunks),
+                       dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)ca.p, nchunks, tb,
+                       minor_bits, col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0, status.p, ticket, merged_out,
+                       oversize, sort_err, (int)ctx->opt_ablate);
+  else
+    hipLaunchKernelGGL((rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItems, kRlDigitBits>), dim3(nchunks),
+                       dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)ca.p, nchunks, tb,
+                       minor_bits, col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0, status.p, ticket, merged_out,
+                       oversize, sort_err, (int)ctx->opt_ablate);
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
 }
