@@ -195,13 +195,14 @@ inline bool use_col32(futhark_context *ctx, int64_t m) { return !ctx->opt_wide_c
 // [begin_bit, end_bit); bits below begin_bit must already be in order within
 // equal upper bits (the CSR->CSC conversion uses that).  err_flag (device int,
 // may be null) is checked at the one host synchronisation point.
-// allow_msd: the caller can pack the keys again; the sort may then try radix_sort_msd.hpp and, if a chunk did not
-// fit, this returns kAssembleAgain with nothing built (the keys are spent): pack again and call with false.
+// allow_msd / allow_retry: the caller can pack the keys again; the sort may then try radix_sort_msd.hpp, and if a
+// chunk did not fit or a look-back wait timed out this returns kAssembleAgain with nothing built (the keys are
+// spent): pack again and call with false, false.
 constexpr int kAssembleAgain = -77;
 template <class K, class T>
 int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_bit, int end_bit, int minor_bits,
                   const T *vals_in, int64_t n_major, int64_t n_minor, const int *err_flag, CsrBody<T> **out,
-                  bool allow_msd = false) {
+                  bool allow_msd = false, bool allow_retry = false) {
   CsrBody<T> *b = new CsrBody<T>();
   CsrGuard<T> guard(ctx, b);
   b->n = n_major;
@@ -297,7 +298,11 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
           SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 1, err_flag, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
         int64_t host[4];
         SAMD_TRY(read_small(ctx, ctx->d_small, 4, host));
-        if ((int)(host[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
+        if (ctx->opt_sort_inject && allow_retry) host[2] = 1;
+        if ((int)(host[2] & 0xffffffff) != 0) {  // a look-back wait ran into its limit (GPU shared or preempted)
+          ctx->last_sort_msd = -2;
+          return kAssembleAgain;
+        }
         if ((int)(host[1] & 0xffffffff) != 0)
           return set_error(ctx, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
         if ((int)(host[3] & 0xffffffff) != 0) {  // a chunk did not fit its workgroup: nothing of this is final
@@ -361,7 +366,12 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
       SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 1, err_flag, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     int64_t host[4];
     SAMD_TRY(read_small(ctx, ctx->d_small, 4, host));
-    if ((int)(host[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
+    if (ctx->opt_sort_inject && allow_retry) host[2] = 1;
+    if ((int)(host[2] & 0xffffffff) != 0) {  // a look-back wait ran into its limit (GPU shared or preempted)
+      if (!allow_retry) return set_error(ctx, "internal: radix sort look-back timed out");
+      ctx->last_sort_msd = -2;
+      return kAssembleAgain;
+    }
     if ((int)(host[1] & 0xffffffff) != 0)
       return set_error(ctx, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
     merged = (int64_t)(uint32_t)(host[0] & 0xffffffffLL);
@@ -427,9 +437,13 @@ int assemble_coo(futhark_context *ctx, int64_t n_major, int64_t n_minor, const i
                          n_major, n_minor, cbits, keys.p, err.p);
       SAMD_LAUNCH_CHECK(ctx);
     }
+    // second attempt (a chunk of the in-LDS sort did not fit, or a look-back wait timed out): the plain LSD sort
+    // with histogram + scan passes, which wait for nothing
+    ctx->sort_force_scan = attempt == 1;
     const int rc = assemble_core<uint64_t, T>(ctx, keys, count, 0, rbits + cbits, cbits, vals, n_major, n_minor, err.p,
-                                              out, attempt == 0);
-    if (attempt == 1) ctx->last_sort_msd = -1;  // tried, did not fit, sorted again
+                                              out, attempt == 0, attempt == 0);
+    ctx->sort_force_scan = false;
+    if (attempt == 1) ctx->last_sort_msd = -1;  // tried, sorted again
     if (rc != kAssembleAgain) return rc;
   }
   return set_error(ctx, "internal: assembly asked to sort again twice");

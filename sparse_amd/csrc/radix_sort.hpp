@@ -386,7 +386,7 @@ int radix_sort_pairs(futhark_context *ctx, K *keys_a, K *keys_b, const P *pay_in
   constexpr int TILE = RsCfg<K, P>::kTile;
   if (n >= (int64_t)0xffff0000LL) return set_error(ctx, "sort: more than 2^32 entries on one device");
   const uint32_t ntiles = (uint32_t)cdiv(n, TILE);
-  if (ctx->opt_sort_algo == 0 && n > 0 && end_bit > begin_bit && end_bit - begin_bit <= 8 * kRsMaxPasses)
+  if (ctx->opt_sort_algo == 0 && !ctx->sort_force_scan && n > 0 && end_bit > begin_bit && end_bit - begin_bit <= 8 * kRsMaxPasses)
     return radix_sort_pairs_onesweep<K, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, begin_bit, end_bit, keys_out,
                                            pay_out, sort_err);
   K *kin = keys_a, *kout = keys_b;

@@ -185,6 +185,20 @@ def test_sparse_top_bits_by_global_passes_rest_in_lds(ctx, dtype, indirect, top,
         ctx.set_option("sort_indirect", 0)
 
 
+def test_sparse_is_sorted_again_without_look_back_after_a_timed_out_wait(ctx):
+    """A look-back wait that runs into its limit (GPU shared or preempted for seconds) no longer fails the assembly:
+    it is repeated with histogram + scan passes, which wait for nothing.  Injected: option sort_inject."""
+    n, m, k = 100000, 100000, 200000
+    r, c, v = random_coo(n, m, k, "f64", seed=5, dup_frac=0.1)
+    O, M = Oracle("f64"), mk(ctx, "f64")
+    ctx.set_option("sort_inject", 1)
+    try:
+        assert_same_record(M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v))
+        assert ctx.get_option("sort_last_msd") == -1
+    finally:
+        ctx.set_option("sort_inject", 0)
+
+
 def test_sparse_rejects_out_of_range(ctx):
     from sparse_amd.compressed import SparseError
     M = mk(ctx, "f64")
