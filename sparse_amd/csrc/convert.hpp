@@ -23,6 +23,30 @@ __global__ __launch_bounds__(kBlock) void coo_kernel(const int64_t *__restrict__
   v_out[e] = vals[e];
 }
 
+// the same, a whole tile per block with the rows from tile_rows (one row_ptr read per row, no search per entry)
+template <class T, class I>
+__global__ __launch_bounds__(kBlock) void coo_tile_kernel(const int64_t *__restrict__ row_ptr, const I *__restrict__ col,
+                                                          const T *__restrict__ vals, int64_t nnz,
+                                                          const int64_t *__restrict__ tile_lb,
+                                                          int64_t *__restrict__ r_out, int64_t *__restrict__ c_out,
+                                                          T *__restrict__ v_out) {
+  __shared__ unsigned mark[4 * kBlock];
+  __shared__ unsigned sh[kWaves];
+  const int64_t t = blockIdx.x;
+  int64_t row[4];
+  tile_rows(row_ptr, tile_lb, t, mark, sh, row);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int64_t e = t * (4 * kBlock) + wave * 256 + k * 64 + lane;
+    if (e < nnz) {
+      r_out[e] = row[k];
+      c_out[e] = (int64_t)col[e];
+      v_out[e] = vals[e];
+    }
+  }
+}
+
 // dense: scatter_2d into a zeroed [n][m] (TRANSPOSED: into [m][n], sc.dense)
 template <class T, class I, bool TRANSPOSED>
 __global__ __launch_bounds__(kBlock) void dense_kernel(const int64_t *__restrict__ row_ptr, const I *__restrict__ col,
@@ -200,6 +224,18 @@ int count_nonzero(futhark_context *ctx, const CsrBody<T> *a, int64_t *out) {
 template <class T>
 int to_coo(futhark_context *ctx, const CsrBody<T> *a, int64_t *r, int64_t *c, T *v) {
   if (a->nnz == 0) return 0;
+  if (a->tile == 4 * kBlock && a->n < 0x7fffffffLL) {
+    if (a->col32)
+      hipLaunchKernelGGL((coo_tile_kernel<T, int32_t>), dim3((unsigned)a->ntiles), dim3(kBlock), 0, ctx->stream,
+                         (const int64_t *)a->row_ptr, (const int32_t *)a->col32, (const T *)a->vals, a->nnz,
+                         (const int64_t *)a->tile_lb, r, c, v);
+    else
+      hipLaunchKernelGGL((coo_tile_kernel<T, int64_t>), dim3((unsigned)a->ntiles), dim3(kBlock), 0, ctx->stream,
+                         (const int64_t *)a->row_ptr, (const int64_t *)a->col64, (const T *)a->vals, a->nnz,
+                         (const int64_t *)a->tile_lb, r, c, v);
+    SAMD_LAUNCH_CHECK(ctx);
+    return 0;
+  }
   const unsigned grid = (unsigned)cdiv(a->nnz, kBlock);
   if (a->col32)
     hipLaunchKernelGGL((coo_kernel<T, int32_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const int64_t *)a->row_ptr,
