@@ -188,6 +188,22 @@ __global__ __launch_bounds__(kBlock) void merge_emit_kernel(const K *__restrict_
   if (!has_next || shr_safe<K>(knext, minor_bits) != major) row_ptr[(int64_t)major + 1] = (int64_t)s;
 }
 
+// The same for keys known to be distinct (a record being transposed): slot = position, nothing to fold, no head
+// flags to scan.
+template <class K, class T, class I>
+__global__ __launch_bounds__(kBlock) void emit_unique_kernel(const K *__restrict__ keys, const uint32_t *__restrict__ perm,
+                                                             const T *__restrict__ vals_in, int64_t count,
+                                                             int minor_bits, K minor_mask, I *__restrict__ col_out,
+                                                             T *__restrict__ vals_out, int64_t *__restrict__ row_ptr) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const K k = keys[i];
+  col_out[i] = (I)(k & minor_mask);
+  vals_out[i] = vals_in[perm ? (int64_t)perm[i] : i];
+  const K major = shr_safe<K>(k, minor_bits);
+  if (i + 1 == count || shr_safe<K>(keys[i + 1], minor_bits) != major) row_ptr[(int64_t)major + 1] = i + 1;
+}
+
 // ---------------------------------------------------------------------- plan
 // tile_lb[ntiles + 1] and [ntiles + 2] (zeroed by the caller) receive two statistics of the plan:
 // the longest first spill (the largest number of entries by which a row runs past the end of the
@@ -250,7 +266,7 @@ constexpr int kAssembleAgain = -77;
 template <class K, class T>
 int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_bit, int end_bit, int minor_bits,
                   const T *vals_in, int64_t n_major, int64_t n_minor, const int *err_flag, CsrBody<T> **out,
-                  bool allow_msd = false, bool allow_retry = false) {
+                  bool allow_msd = false, bool allow_retry = false, bool unique_keys = false) {
   CsrBody<T> *b = new CsrBody<T>();
   CsrGuard<T> guard(ctx, b);
   b->n = n_major;
@@ -405,6 +421,32 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
       vs = reinterpret_cast<const T *>(sorted_val);
     }
 
+    if (unique_keys) {  // no two keys are equal (conversion of a record): positions are slots
+      b->nnz = count;
+      SAMD_TRY(dalloc(ctx, &b->vals, count));
+      const K mmask = minor_bits >= (int)(sizeof(K) * 8) ? (K)~(K)0 : (K)(((K)1 << minor_bits) - 1);
+      const unsigned ugrid = (unsigned)cdiv(count, kBlock);
+      if (use_col32(ctx, n_minor)) {
+        SAMD_TRY(dalloc(ctx, &b->col32, count));
+        hipLaunchKernelGGL((emit_unique_kernel<K, T, int32_t>), dim3(ugrid), dim3(kBlock), 0, ctx->stream, (const K *)ks,
+                           perm, vs, count, minor_bits, mmask, b->col32, b->vals, b->row_ptr);
+      } else {
+        SAMD_TRY(dalloc(ctx, &b->col64, count));
+        hipLaunchKernelGGL((emit_unique_kernel<K, T, int64_t>), dim3(ugrid), dim3(kBlock), 0, ctx->stream, (const K *)ks,
+                           perm, vs, count, minor_bits, mmask, b->col64, b->vals, b->row_ptr);
+      }
+      SAMD_LAUNCH_CHECK(ctx);
+      if (n_major > 0)
+        SAMD_TRY((device_scan<int64_t, OpMax, PtrIn<int64_t>, false>(ctx, PtrIn<int64_t>{b->row_ptr + 1}, n_major,
+                                                                      (int64_t)0, OpMax(), b->row_ptr + 1,
+                                                                      (int64_t *)nullptr)));
+      int64_t flags[1];
+      SAMD_TRY(read_small(ctx, ctx->d_small + 2, 1, flags));  // the sort's look-back flag; also keeps the temporaries alive until the work is done
+      if ((int)(flags[0] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
+      SAMD_TRY(build_plan(ctx, b));
+      *out = guard.release();
+      return 0;
+    }
     // head flags -> slots; total -> host (the only synchronisation of an assembly)
     uint32_t *slots = slot.p;
     SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t) * 2, ctx->stream));
@@ -537,12 +579,13 @@ int transpose_physical(futhark_context *ctx, const CsrBody<T> *a, CsrBody<T> **o
     SAMD_TRY(keys.get(a->nnz));
     SAMD_TRY((pack_csr<uint32_t, T, true>(ctx, a, rbits, keys.p)));
     return assemble_core<uint32_t, T>(ctx, keys, a->nnz, rbits, rbits + cbits, rbits, a->vals, a->m, a->n, nullptr,
-                                      out);
+                                      out, false, false, true);
   }
   Tmp<uint64_t> keys(ctx);
   SAMD_TRY(keys.get(a->nnz));
   SAMD_TRY((pack_csr<uint64_t, T, true>(ctx, a, rbits, keys.p)));
-  return assemble_core<uint64_t, T>(ctx, keys, a->nnz, rbits, rbits + cbits, rbits, a->vals, a->m, a->n, nullptr, out);
+  return assemble_core<uint64_t, T>(ctx, keys, a->nnz, rbits, rbits + cbits, rbits, a->vals, a->m, a->n, nullptr, out,
+                                    false, false, true);
 }
 
 // sr.+ / sr.- : (coo a ++ coo (scale -1 b)) |> sparse n m  (compressed.fut:179-183)
