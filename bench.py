@@ -109,6 +109,10 @@ def c5_leg(args, torch, dist, world, rank, dev, ctx, M):
     n, total = args.c5_n, args.c5_triples
     lo, hi = total * rank // world, total * (rank + 1) // world
     r, c, v = synth.random_uniform_coo_counter_device(n, n, lo, hi - lo, dev, integer_values=True)
+    # once untimed: the first assembly of this size pays for the device allocations behind the library's pool and
+    # torch's (hipMalloc of tens of GB) and for RCCL's connections
+    D = sd.DistCsr.from_coo_chunks(M, dist, n, n, r, c, v)
+    del D
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

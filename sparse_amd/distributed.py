@@ -113,6 +113,8 @@ def coarse_row_splitters(dist, n_glob, rs, parts, bins_log2=16):
     row histogram (<= 2^bins_log2 bins, one all-reduce).  rs: this rank's row ids (any
     device).  Every rank returns the same parts+1 ascending boundaries."""
     import torch
+    if parts == 1:
+        return [0, n_glob]
     shift = max(0, int(n_glob - 1).bit_length() - bins_log2) if n_glob > 0 else 0
     nb = ((n_glob - 1) >> shift) + 1 if n_glob > 0 else 1
     h = torch.bincount(rs >> shift, minlength=nb).to(torch.int64) if rs.numel() else \
@@ -148,9 +150,17 @@ def redistribute_coo(dist, bounds, rs, cs, vs):
     dist.all_gather(allc, counts)
     send_counts = [int(v) for v in counts.tolist()]
     recv_counts = [int(allc[p][rank].item()) for p in range(world)]
+    # one stable sort of the destinations (source order kept inside each part), then one gather per array
+    # instead of a boolean select per (array, destination)
+    order = torch.argsort(dest, stable=True)
+    offs = [0]
+    for k in send_counts:
+        offs.append(offs[-1] + k)
+    del dest
     outs = []
     for arr in (rs, cs, vs):
-        parts = [arr[dest == p].contiguous() for p in range(world)]       # boolean select keeps source order
+        packed = arr.index_select(0, order)
+        parts = [packed[offs[p]:offs[p + 1]] for p in range(world)]
         recv = [parts[p] if p == rank else torch.empty(recv_counts[p], dtype=arr.dtype, device=dev)
                 for p in range(world)]
         ops = []
@@ -165,7 +175,7 @@ def redistribute_coo(dist, bounds, rs, cs, vs):
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         outs.append(torch.cat(recv))
-        del parts, recv
+        del parts, recv, packed
     return tuple(outs)
 
 
@@ -382,7 +392,7 @@ class DistCsr:
         del needed
         n_loc = row_hi - row_lo
         if plan.mode != "halo" or not split:
-            A = M.sr.sparse(n_loc, plan.x_len, (rs - row_lo, plan.remap_cols(cs), vs))
+            A = M.sr.sparse(n_loc, plan.x_len, (rs - row_lo if row_lo else rs, plan.remap_cols(cs), vs))
             return cls(M, plan, A, n_loc, vs.dtype)
         own = (cs >= plan.lo) & (cs < plan.hi)
         A = M.sr.sparse(n_loc, plan.n_own, ((rs[own] - row_lo).contiguous(), (cs[own] - plan.lo).contiguous(),
