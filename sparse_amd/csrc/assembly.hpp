@@ -307,7 +307,7 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
       if (allow_msd && begin_bit == 0 && end_bit <= 64 - kRlTagBits)
         SAMD_TRY(msd_choose<K>(ctx, keys.p, count, begin_bit, end_bit, RlEmitCfg<T>::kCap, RlEmitCfg<T>::kCapSmall, &msd_tb,
                                &msd_ch, &msd_small, &far));
-      if (msd_tb > 40) msd_tb = -1;  // composite = ordinal (<= 11 bits) | low bits | 13-bit tag
+      if (msd_tb > 38) msd_tb = -1;  // composite = ordinal (<= 12 bits) | low bits | 13-bit tag, in 64 bits
     }
     if (sample_far) {
       if (far < 0) SAMD_TRY(read_small(ctx, ctx->d_small + 8, 1, &far));

@@ -387,7 +387,17 @@ class DistCsr:
         else:
             per = -(-m_glob // world)
             bounds = [min(k * per, m_glob) for k in range(world)] + [m_glob]
-        needed = torch.unique(cs) if world > 1 else cs[:0]      # a single rank exchanges nothing: skip the sort
+        # the columns this rank's rows reference, ascending.  A single rank exchanges nothing; otherwise a byte
+        # mask over the columns (one scatter, one compaction) is cheaper than sorting the ids when it fits
+        if world == 1:
+            needed = cs[:0]
+        elif m_glob <= (1 << 31):
+            mask = torch.zeros(m_glob, dtype=torch.bool, device=dev)
+            mask[cs] = True
+            needed = mask.nonzero().flatten()
+            del mask
+        else:
+            needed = torch.unique(cs)
         plan = ExchangePlan(dist, bounds, needed, dev, force_mode)
         del needed
         n_loc = row_hi - row_lo

@@ -223,3 +223,44 @@ def test_c3_two_pass_product_is_chosen_and_within_tolerance():
     yi = torch.as_tensor(Mi.sr.smvm(Mi.sr.sparse(n, n, (r, c, vi)), xi), device="cuda:0")
     assert ctx.get_option("spmv_last_path") == 3
     assert torch.equal(yi, yi2)
+
+
+@pytest.mark.parametrize("dtype,sorted_input", [("f32", False), ("i32", False), ("f64", False), ("f64", True)])
+def test_assembly_second_sort_equals_the_lsd_sort_at_scale(dtype, sorted_input):
+    """3e7 uniform random triples on 4e6 x 4e6 (44 key bits, ~0.01 % duplicate coordinates): in auto mode the
+    assembly takes the top key bits through global passes and sorts, folds and writes the rest from LDS
+    (radix_sort_msd.hpp); with sort_msd -1 it is the plain LSD sort + merge_emit, which the oracle pins at small
+    sizes.  The two records must be equal bit for bit -- 4-byte values, 8-byte values carried with their keys, and
+    (sorted input) 8-byte values fetched through their source index."""
+    torch, ctx = _ctx()
+    from sparse_amd import mk_compressed
+    M = mk_compressed(dtype, ctx)
+    n = m = 4 * 10**6
+    k = 3 * 10**7
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(11)
+    r = torch.randint(0, n, (k,), device="cuda:0", generator=g)
+    c = torch.randint(0, m, (k,), device="cuda:0", generator=g)
+    if dtype == "i32":
+        v = torch.randint(-9, 10, (k,), device="cuda:0", generator=g, dtype=torch.int32)
+    else:
+        v = torch.rand(k, device="cuda:0", generator=g, dtype=torch.float32 if dtype == "f32" else torch.float64) - 0.5
+    if sorted_input:
+        o = torch.argsort(r * m + c, stable=True)
+        r, c, v = r[o].contiguous(), c[o].contiguous(), v[o].contiguous()
+        del o
+    A = M.sr.sparse(n, m, (r, c, v))
+    assert ctx.get_option("sort_last_msd") in (16, 24), "the second sort was not chosen"
+    ctx.set_option("sort_msd", -1)
+    try:
+        B = M.sr.sparse(n, m, (r, c, v))
+        assert ctx.get_option("sort_last_msd") == 0
+    finally:
+        ctx.set_option("sort_msd", 0)
+    assert A.stored_dims() == B.stored_dims() and A.stored_dims()[2] < k
+    for fa, fb in zip(A.fields(), B.fields()):
+        ta, tb = torch.as_tensor(fa, device="cuda:0"), torch.as_tensor(fb, device="cuda:0")
+        if ta.dtype.is_floating_point:
+            ta, tb = ta.view(torch.int32 if ta.element_size() == 4 else torch.int64), \
+                tb.view(torch.int32 if tb.element_size() == 4 else torch.int64)
+        assert torch.equal(ta, tb)
