@@ -145,6 +145,65 @@ __global__ __launch_bounds__(kBlock) void displacement_sample_kernel(const K *__
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
 }
 
+// ---------------------------------------------------------------- two sorted runs -> one
+// sr.+ / sr.- concatenate the entries of two records (compressed.fut:179-183): each half is already in key order, so
+// the stable sort of the concatenation is a stable MERGE (first run before second on equal keys).  Merge path: a
+// workgroup owns kMergeTile consecutive outputs, finds where its diagonal cuts the two runs (binary search in
+// global memory, once per workgroup), stages exactly those kMergeTile keys in LDS, and every thread merges its 8
+// outputs after a second search in LDS.  Also writes each output's position in the concatenation (the value's source).
+constexpr int kMergeItems = 8;
+constexpr int kMergeTile = kBlock * kMergeItems;
+
+template <class K, class A, class B>
+__device__ __forceinline__ int64_t merge_path_split(const A &a, int64_t na, const B &b, int64_t nb, int64_t d) {
+  int64_t lo = d > nb ? d - nb : 0, hi = d < na ? d : na;  // number of first-run elements among the first d outputs
+  while (lo < hi) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (a(mid) <= b(d - 1 - mid)) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <class K>
+__global__ __launch_bounds__(kBlock) void merge_runs_kernel(const K *__restrict__ keys, int64_t na, int64_t nb,
+                                                            K *__restrict__ keys_out, uint32_t *__restrict__ src_out) {
+  __shared__ K sk[kMergeTile];
+  __shared__ int64_t s_split[2];
+  const int tid = threadIdx.x;
+  const int64_t total = na + nb;
+  const int64_t d0 = (int64_t)blockIdx.x * kMergeTile;
+  const int64_t d1 = d0 + kMergeTile < total ? d0 + kMergeTile : total;
+  const K *ka = keys, *kb = keys + na;
+  if (tid < 2) {
+    auto ga = [&](int64_t i) { return ka[i]; };
+    auto gb = [&](int64_t j) { return kb[j]; };
+    s_split[tid] = merge_path_split<K>(ga, na, gb, nb, tid == 0 ? d0 : d1);
+  }
+  __syncthreads();
+  const int64_t i0 = s_split[0], i1 = s_split[1];
+  const int64_t j0 = d0 - i0, j1 = d1 - i1;
+  const int la = (int)(i1 - i0), lb = (int)(j1 - j0);  // la + lb = d1 - d0 <= kMergeTile
+  for (int q = tid; q < la; q += kBlock) sk[q] = ka[i0 + q];
+  for (int q = tid; q < lb; q += kBlock) sk[la + q] = kb[j0 + q];
+  __syncthreads();
+  const int ld = tid * kMergeItems;
+  if (ld >= la + lb) return;
+  auto sa = [&](int64_t i) { return sk[i]; };
+  auto sb = [&](int64_t j) { return sk[la + j]; };
+  int ia = (int)merge_path_split<K>(sa, la, sb, lb, ld);
+  int ib = ld - ia;
+#pragma unroll
+  for (int q = 0; q < kMergeItems; q++) {
+    if (ld + q >= la + lb) break;
+    const bool take_a = ib >= lb || (ia < la && sk[ia] <= sk[la + ib]);
+    const K k = take_a ? sk[ia] : sk[la + ib];
+    const int64_t src = take_a ? i0 + ia : na + j0 + ib;
+    keys_out[d0 + ld + q] = k;
+    src_out[d0 + ld + q] = (uint32_t)src;
+    if (take_a) ia++; else ib++;
+  }
+}
+
 // ---------------------------------------------------------------- merge / emit
 template <class K>
 struct HeadFlagIn {
@@ -266,7 +325,8 @@ constexpr int kAssembleAgain = -77;
 template <class K, class T>
 int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_bit, int end_bit, int minor_bits,
                   const T *vals_in, int64_t n_major, int64_t n_minor, const int *err_flag, CsrBody<T> **out,
-                  bool allow_msd = false, bool allow_retry = false, bool unique_keys = false) {
+                  bool allow_msd = false, bool allow_retry = false, bool unique_keys = false,
+                  int64_t sorted_runs_split = -1) {  // >= 0: keys[0, split) and keys[split, count) are each in order
   CsrBody<T> *b = new CsrBody<T>();
   CsrGuard<T> guard(ctx, b);
   b->n = n_major;
@@ -287,7 +347,7 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     typedef typename BitsOf<T>::type VB;
     bool indirect = sizeof(T) > 4;
     if (sizeof(T) > 4 && ctx->opt_sort_indirect < 0) indirect = false;
-    const bool sample_far = sizeof(T) > 4 && ctx->opt_sort_indirect == 0 && count >= (1 << 20) && end_bit - begin_bit > 16;
+    const bool sample_far = sorted_runs_split < 0 && sizeof(T) > 4 && ctx->opt_sort_indirect == 0 && count >= (1 << 20) && end_bit - begin_bit > 16;
     if (sample_far) {
       SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 8, 0, sizeof(int64_t), ctx->stream));
       const double keyspace = ldexp((double)(n_major > 0 ? n_major : 1), minor_bits);
@@ -404,7 +464,15 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
         return 0;
       }
     }
-    if (indirect) {
+    if (sorted_runs_split >= 0) {  // two runs in order: a stable merge is the stable sort
+      SAMD_TRY(pay_a.get(count));
+      hipLaunchKernelGGL((merge_runs_kernel<K>), dim3((unsigned)cdiv(count, kMergeTile)), dim3(kBlock), 0, ctx->stream,
+                         (const K *)keys.p, sorted_runs_split, count - sorted_runs_split, keys_b.p, pay_a.p);
+      SAMD_LAUNCH_CHECK(ctx);
+      ks = keys_b.p;
+      perm = pay_a.p;
+      vs = vals_in;
+    } else if (indirect) {
       const uint32_t *sorted_pay = nullptr;
       SAMD_TRY(pay_a.get(count));
       SAMD_TRY(pay_b.get(count));
@@ -594,6 +662,8 @@ int add_sub(futhark_context *ctx, const CsrBody<T> *a, const CsrBody<T> *b, bool
   if (a->n != b->n || a->m != b->m) return set_error(ctx, "add/sub: shape mismatch");
   const int64_t tot = a->nnz + b->nnz;
   const int rbits = bits_for(a->n), cbits = bits_for(a->m);
+  // the two halves of the concatenation are in key order: merged, not sorted (option add_sort = 1: the sort, for comparison)
+  const int64_t split = (ctx->opt_add_sort || tot >= 0xffffffffLL) ? -1 : a->nnz;
   Tmp<T> vals(ctx);
   SAMD_TRY(vals.get(tot));
   if (tot > 0) {
@@ -606,13 +676,15 @@ int add_sub(futhark_context *ctx, const CsrBody<T> *a, const CsrBody<T> *b, bool
     SAMD_TRY(keys.get(tot));
     SAMD_TRY((pack_csr<uint32_t, T, false>(ctx, a, cbits, keys.p)));
     SAMD_TRY((pack_csr<uint32_t, T, false>(ctx, b, cbits, keys.p + a->nnz)));
-    return assemble_core<uint32_t, T>(ctx, keys, tot, 0, rbits + cbits, cbits, vals.p, a->n, a->m, nullptr, out);
+    return assemble_core<uint32_t, T>(ctx, keys, tot, 0, rbits + cbits, cbits, vals.p, a->n, a->m, nullptr, out, false,
+                                      false, false, split);
   }
   Tmp<uint64_t> keys(ctx);
   SAMD_TRY(keys.get(tot));
   SAMD_TRY((pack_csr<uint64_t, T, false>(ctx, a, cbits, keys.p)));
   SAMD_TRY((pack_csr<uint64_t, T, false>(ctx, b, cbits, keys.p + a->nnz)));
-  return assemble_core<uint64_t, T>(ctx, keys, tot, 0, rbits + cbits, cbits, vals.p, a->n, a->m, nullptr, out);
+  return assemble_core<uint64_t, T>(ctx, keys, tot, 0, rbits + cbits, cbits, vals.p, a->n, a->m, nullptr, out, false, false,
+                                    false, split);
 }
 
 }  // namespace samd

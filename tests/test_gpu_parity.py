@@ -637,6 +637,36 @@ def test_coo_dense_nnz_scale_addsub_conversion(ctx, dtype):
     assert np.array_equal(M.sc.dense(M.sr.transpose(A)).numpy(), O.sr_dense(Ao).T)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+@pytest.mark.parametrize("shape", [(3000, 2000, 70000, 50000), (5, 100000, 60000, 1), (100000, 100000, 40000, 90000),
+                                   (64, 64, 4096, 0), (1 << 17, 1 << 33, 50000, 50000)],
+                         ids=["overlapping", "one_entry_second", "second_longer", "empty_second", "wide_keys"])
+def test_add_sub_merge_the_two_records_against_the_oracle(ctx, dtype, shape):
+    """sr.+ / sr.- = sparse (coo a ++ coo (scale -1 b)) (compressed.fut:179-183).  Both halves are in key order, so the
+    library merges them (merge path) instead of sorting: same record as the oracle, and as its own sort (add_sort)."""
+    n, m, ka, kb = shape
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    ra = (synth.splitmix64(1, np.arange(ka, dtype=np.uint64)) % np.uint64(n)).astype(np.int64)
+    ca = (synth.splitmix64(2, np.arange(ka, dtype=np.uint64)) % np.uint64(m)).astype(np.int64)
+    va = synth.uniform_values(3, ka, dtype)
+    # the second record shares about half of its coordinates with the first
+    kb_sh = min(kb // 2, ka)
+    rb = np.concatenate([ra[:kb_sh], (synth.splitmix64(4, np.arange(kb - kb_sh, dtype=np.uint64)) % np.uint64(n)).astype(np.int64)])
+    cb = np.concatenate([ca[:kb_sh], (synth.splitmix64(5, np.arange(kb - kb_sh, dtype=np.uint64)) % np.uint64(m)).astype(np.int64)])
+    vb = synth.uniform_values(6, kb, dtype)
+    A, Ao = M.sr.sparse(n, m, (ra, ca, va)), O.sr_sparse(n, m, ra, ca, va)
+    B, Bo = M.sr.sparse(n, m, (rb, cb, vb)), O.sr_sparse(n, m, rb, cb, vb)
+    for op, oop in ((M.sr.add, O.sr_add), (M.sr.sub, O.sr_sub)):
+        want = oop(Ao, Bo)
+        assert_same_record(op(A, B), want)
+        assert_same_record(op(B, A), oop(Bo, Ao))
+        ctx.set_option("add_sort", 1)
+        try:
+            assert_same_record(op(A, B), want)
+        finally:
+            ctx.set_option("add_sort", 0)
+
+
 @pytest.mark.parametrize("dtype", ["f64", "i32"])
 def test_constructors(ctx, dtype):
     O, M = Oracle(dtype), mk(ctx, dtype)
