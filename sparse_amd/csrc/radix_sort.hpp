@@ -22,6 +22,8 @@
 // scan.hpp so every load is a coalesced 64-lane row.
 #pragma once
 
+#include <vector>
+
 #include "scan.hpp"
 
 namespace samd {
@@ -204,14 +206,34 @@ __global__ __launch_bounds__(kBlock) void rs_scan_hist(uint32_t *__restrict__ gh
   ghist[blockIdx.x * kRsRadix + threadIdx.x] = ex;
 }
 
+// Where a tile's digit runs go = the digit's global base + the counts of that digit in all earlier tiles.  The
+// earlier tiles' counts come from a decoupled look-back, laid out for what it costs on this machine: device-scope
+// loads go past the per-XCD L2, and with one 8-byte status word per (tile, digit) the walk (about 50 tiles back
+// before an inclusive prefix is out, never an unpublished word: bench/sweep_lab.sh) read as many bytes as the tile
+// itself -- 0.92 ms per pass on C2's 16-byte pairs with it, 0.50 without.  So:
+//   agg[tile][digit]   u16  the tile's own count | 0x8000, published right after a plain LDS histogram of the keys
+//                           (before the expensive ranking); 0 = not there yet, 0xffff = poisoned
+//   incl[group][digit] u32  1 + count of the digit in all tiles up to the end of group `group` (16 tiles), published
+//                           by the group's last tile only; 0 = not there yet, 0xffffffff = poisoned
+// and a tile adds up, group by group going back, the 2-byte counts of the tiles before it until it meets a group
+// whose inclusive prefix is out: one round trip per group, ~70 bytes per digit instead of ~460.  Collected as late
+// as possible (the tile is already re-ordered in LDS), so slower predecessors have had time.
+// Tiles are handed out through a ticket counter so that every tile a block waits for has already started; a wait
+// that lasts longer than kRsSpinLimit poisons the chain and raises *err, so every wave reaches its exit.
+constexpr int kRsGroup = 16;
+constexpr uint16_t kRsAggReady = 0x8000, kRsAggPoison = 0xffff;
+constexpr uint32_t kRsInclPoison = 0xffffffffu;
+
 template <class K, class P, int ITEMS, bool IOTA>
 __global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin, const P *__restrict__ pin,
                                                       K *__restrict__ kout, P *__restrict__ pout, uint32_t n,
                                                       int shift, uint32_t mask, const uint32_t *__restrict__ gbase,
-                                                      unsigned long long *__restrict__ status,
-                                                      uint32_t *__restrict__ ticket, int *__restrict__ err) {
+                                                      uint16_t *__restrict__ agg, uint32_t *__restrict__ incl,
+                                                      uint32_t *__restrict__ ticket, int *__restrict__ err, int lab) {
   constexpr int TILE = kBlock * ITEMS;
+  static_assert(TILE < 0x8000, "a tile's digit count must fit 15 bits");
   __shared__ uint32_t cnt[kWaves][kRsRadix];
+  __shared__ uint32_t hcnt[kRsRadix];
   __shared__ uint32_t lstart[kRsRadix];
   __shared__ uint32_t goff[kRsRadix];
   __shared__ uint32_t shs[kWaves];
@@ -226,10 +248,12 @@ __global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin,
     s_fail = 0;
   }
   for (int d = tid; d < kWaves * kRsRadix; d += kBlock) (&cnt[0][0])[d] = 0;
+  hcnt[tid] = 0;
   __syncthreads();
   const uint32_t tile = s_tile;
 
   const uint32_t tile_base = tile * (uint32_t)TILE;
+  const uint32_t valid = (n - tile_base) < (uint32_t)TILE ? (n - tile_base) : (uint32_t)TILE;
   const uint32_t base = tile_base + wave * (ITEMS * 64) + lane;
   K key[ITEMS];
   P pay[ITEMS];
@@ -238,16 +262,37 @@ __global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin,
   for (int k = 0; k < ITEMS; k++) {
     uint32_t i = base + k * 64;
     bool ok = i < n;
-    key[k] = ok ? kin[i] : (K)~(K)0;
+    key[k] = ok ? kin[i] : (K)~(K)0;  // padding sorts to the very end of the tile
     pay[k] = ok ? (IOTA ? (P)i : pin[i]) : (P)0;
   }
+  // ---- the tile's digit counts, and out with them (one add per run of equal neighbouring digits, see rs_hist_all)
+#pragma unroll
+  for (int k = 0; k < ITEMS; k++) {
+    const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
+    const uint32_t before = wshfl_up(d, 1);
+    const bool head = lane == 0 || d != before;
+    const uint64_t hm = __ballot(head);
+    if (head) {
+      const uint64_t rest = lane == 63 ? 0ull : (hm >> (lane + 1));
+      atomicAdd(&hcnt[d], rest ? (uint32_t)__builtin_ctzll(rest) + 1u : (uint32_t)(64 - lane));
+    }
+  }
+  __syncthreads();
+  // padding keys of the last tile were counted under digit `mask` of an all-ones key: take them out of what is
+  // published (they are not written either)
+  uint32_t pub = hcnt[tid];
+  if ((uint32_t)tid == mask && valid < (uint32_t)TILE) pub -= (uint32_t)TILE - valid;
+  uint16_t *mine = agg + (size_t)tile * kRsRadix + tid;
+  __hip_atomic_store(mine, (uint16_t)(kRsAggReady | pub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // ---- rank every pair inside its wavefront (ballot match-any), wavefront counters in LDS
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int k = 0; k < ITEMS; k++) {
     const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
     uint64_t peers = ~0ull;
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < ((lab & 0x2000) ? 0 : 8); b++) {  // lab 0x2000: no match-any (wrong ranks)
       const bool bit = (d >> b) & 1u;
       const uint64_t bal = __ballot(bit);
       peers &= bit ? bal : ~bal;
@@ -267,68 +312,95 @@ __global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin,
     cnt[w][tid] = tot;
     tot += c;
   }
-  // padding keys of the last tile were counted under digit `mask` of an all-ones key: take them out
-  // of what is published (they are not written either)
-  uint32_t pub = tot;
-  {
-    const uint32_t valid0 = (n - tile_base) < (uint32_t)TILE ? (n - tile_base) : (uint32_t)TILE;
-    if ((uint32_t)tid == mask && valid0 < (uint32_t)TILE) pub = tot - ((uint32_t)TILE - valid0);
-  }
   uint32_t block_total;
   const uint32_t ex = block_exclusive_add<uint32_t>(tot, shs, block_total);
   lstart[tid] = ex;
-
-  // ---- look back over the earlier tiles for digit `tid`
-  unsigned long long excl = 0;
-  unsigned long long *mine = status + (size_t)tile * kRsRadix + tid;
-  if (tile == 0) {
-    __hip_atomic_store(mine, kRsFlagIncl | (unsigned long long)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    __hip_atomic_store(mine, kRsFlagAgg | (unsigned long long)pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int64_t t = (int64_t)tile - 1;
-    const unsigned long long t0 = wall_clock64();
-    bool fail = false;
-    while (true) {
-      const unsigned long long w =
-          __hip_atomic_load(status + (size_t)t * kRsRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long f = w >> 62;
-      if (f == 0) {
-        if (wall_clock64() - t0 > kRsSpinLimit) { fail = true; break; }
-        __builtin_amdgcn_s_sleep(1);
-        continue;
-      }
-      if (f == 3) { fail = true; break; }
-      excl += w & kRsValMask;
-      if (f == 2) break;
-      t--;
-    }
-    if (fail) {
-      s_fail = 1;
-      *err = 1;
-      __hip_atomic_store(mine, kRsFlagPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(mine, kRsFlagIncl | (excl + pub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  goff[tid] = gbase[tid] + (uint32_t)excl - ex;
   __syncthreads();
-  if (s_fail) return;  // uniform: nothing of this tile is written
 #pragma unroll
   for (int k = 0; k < ITEMS; k++) {
     const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
-    const uint32_t p = lstart[d] + cnt[wave][d] + rank[k];
+    uint32_t p = lstart[d] + cnt[wave][d] + rank[k];
+    if (lab & 0x2000) p = (uint32_t)(wave * (ITEMS * 64) + k * 64 + lane);  // lab: ranks are not computed, keep the slot in range
     skey[p] = key[k];
     spay[p] = pay[k];
   }
+
+  // ---- look back, for digit `tid`
+  uint32_t excl = 0;
+  if (!(lab & 0x8000)) {  // lab 0x8000 (with 0x4000: the offsets are not used): no look-back
+    const uint32_t grp = tile / kRsGroup;
+    const unsigned long long t0 = wall_clock64();
+    bool fail = false, done = false;
+    uint32_t rounds = 0, idle = 0;
+    // round r: the counts of the tiles of group grp - r that lie before this one, and the inclusive prefix of group
+    // grp - r - 1, requested together (one round trip, 36 bytes per digit; a walk is 3.8 rounds on average on C2).
+    // Measured and worse, because the cost follows the bytes these loads and stores move, not the round trips: four
+    // groups ahead per round trip (0.82 -> 0.95 ms per pass), 64 eight-byte words per round trip in the first layout
+    // (0.92 -> 1.26), every walking tile putting out the prefixes it has just learnt (3.8 -> 3.1 rounds, 0.82 -> 0.87).
+    for (uint32_t r = 0; !done && !fail; r++) {
+      const uint32_t g = grp - r;
+      const uint32_t first_t = g * kRsGroup;
+      const uint32_t end_t = r == 0 ? tile : first_t + kRsGroup;  // exclusive
+      while (true) {
+        rounds++;
+        uint16_t w[kRsGroup];
+#pragma unroll
+        for (int j = 0; j < kRsGroup; j++)
+          w[j] = first_t + j < end_t ? __hip_atomic_load(agg + (size_t)(first_t + j) * kRsRadix + tid, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT)
+                                     : kRsAggReady;
+        const uint32_t iw = g > 0 ? __hip_atomic_load(incl + (size_t)(g - 1) * kRsRadix + tid, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT)
+                                  : 1u;  // before group 0: an inclusive prefix of nothing
+        bool all = true;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < kRsGroup; j++) {
+          if (w[j] == 0) all = false;
+          if (w[j] == kRsAggPoison) fail = true;
+          sum += w[j] & 0x7fffu;
+        }
+        if (iw == kRsInclPoison) fail = true;
+        if (fail) break;
+        if (all) {
+          excl += sum;
+          if (iw != 0) {
+            excl += iw - 1u;
+            done = true;
+          }
+          break;
+        }
+        idle++;
+        if (wall_clock64() - t0 > kRsSpinLimit) { fail = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if ((lab & 0x40000) && tid == 0) {  // lab: how long the walks are (printed by the host)
+      atomicAdd(ticket + 1, rounds);
+      atomicAdd(ticket + 2, idle);
+      atomicMax(ticket + 3, rounds);
+    }
+    const bool closes = tile % kRsGroup == kRsGroup - 1;  // the group's last tile publishes the group's inclusive prefix
+    if (fail) {
+      s_fail = 1;
+      *err = 1;
+      __hip_atomic_store(mine, kRsAggPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (closes) __hip_atomic_store(incl + (size_t)grp * kRsRadix + tid, kRsInclPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (closes) {
+      __hip_atomic_store(incl + (size_t)grp * kRsRadix + tid, excl + pub + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  goff[tid] = gbase[tid] + excl - ex;
   __syncthreads();
-  const uint32_t valid = (n - tile_base) < (uint32_t)TILE ? (n - tile_base) : (uint32_t)TILE;
+  if (s_fail) return;  // uniform: nothing of this tile is written
 #pragma unroll
   for (int k = 0; k < ITEMS; k++) {
     const uint32_t i = k * kBlock + tid;
     if (i < valid) {
       const K kk = skey[i];
       const uint32_t d = (uint32_t)(kk >> shift) & mask;
-      const uint32_t g = goff[d] + i;
+      // lab 0x4000: contiguous stores (also forced by 0x2000 and 0x8000, whose offsets mean nothing)
+      const uint32_t g = (lab & 0xe000) ? tile_base + i : goff[d] + i;
       kout[g] = kk;
       pout[g] = spay[i];
     }
@@ -343,10 +415,13 @@ int radix_sort_pairs_onesweep(futhark_context *ctx, K *keys_a, K *keys_b, const 
   const uint32_t ntiles = (uint32_t)cdiv(n, TILE);
   const int passes = (end_bit - begin_bit + 7) / 8;
   Tmp<uint32_t> ghist(ctx);                 // [passes][256] digit bases, then one ticket counter per pass
-  Tmp<unsigned long long> status(ctx);      // [ntiles][256], cleared before every pass
-  const int64_t gcount = (int64_t)passes * kRsRadix + passes;
+  Tmp<uint16_t> agg(ctx);                   // [ntiles][256] tile counts, cleared before every pass
+  Tmp<uint32_t> incl(ctx);                  // [groups][256] inclusive prefixes at group ends, likewise
+  const int64_t gcount = (int64_t)passes * kRsRadix + 4 * passes;  // per pass: ticket + three lab counters
   SAMD_TRY(ghist.get(gcount));
-  SAMD_TRY(status.get((int64_t)ntiles * kRsRadix));
+  const int64_t ngroups = cdiv((int64_t)ntiles, kRsGroup);
+  SAMD_TRY(agg.get((int64_t)ntiles * kRsRadix));
+  SAMD_TRY(incl.get(ngroups * kRsRadix));
   SAMD_HIP(ctx, hipMemsetAsync(ghist.p, 0, sizeof(uint32_t) * (size_t)gcount, ctx->stream));
   {
     const int64_t cap = (int64_t)ctx->num_cu * 8;
@@ -364,20 +439,30 @@ int radix_sort_pairs_onesweep(futhark_context *ctx, K *keys_a, K *keys_b, const 
     const int shift = begin_bit + 8 * p;
     const int nb = end_bit - shift < 8 ? end_bit - shift : 8;
     const uint32_t mask = (1u << nb) - 1u;
-    SAMD_HIP(ctx, hipMemsetAsync(status.p, 0, sizeof(unsigned long long) * (size_t)ntiles * kRsRadix, ctx->stream));
+    SAMD_HIP(ctx, hipMemsetAsync(agg.p, 0, sizeof(uint16_t) * (size_t)ntiles * kRsRadix, ctx->stream));
+    SAMD_HIP(ctx, hipMemsetAsync(incl.p, 0, sizeof(uint32_t) * (size_t)ngroups * kRsRadix, ctx->stream));
     const uint32_t *gbase = ghist.p + p * kRsRadix;
-    uint32_t *ticket = ghist.p + passes * kRsRadix + p;
+    uint32_t *ticket = ghist.p + passes * kRsRadix + 4 * p;
     if (pin == nullptr)
       hipLaunchKernelGGL((rs_onesweep<K, P, ITEMS, true>), dim3(ntiles), dim3(kBlock), 0, ctx->stream, (const K *)kin,
-                         pin, kout, pout, (uint32_t)n, shift, mask, gbase, status.p, ticket, err);
+                         pin, kout, pout, (uint32_t)n, shift, mask, gbase, agg.p, incl.p, ticket, err, (int)ctx->opt_ablate);
     else
       hipLaunchKernelGGL((rs_onesweep<K, P, ITEMS, false>), dim3(ntiles), dim3(kBlock), 0, ctx->stream, (const K *)kin,
-                         pin, kout, pout, (uint32_t)n, shift, mask, gbase, status.p, ticket, err);
+                         pin, kout, pout, (uint32_t)n, shift, mask, gbase, agg.p, incl.p, ticket, err, (int)ctx->opt_ablate);
     SAMD_LAUNCH_CHECK(ctx);
     K *tk = kin; kin = kout; kout = tk;
     P *written = pout;
     pout = (written == pay_a) ? pspare : pay_a;
     pin = written;
+  }
+  if (ctx->opt_ablate & 0x40000) {  // lab: look-back statistics of every pass
+    std::vector<uint32_t> h((size_t)4 * passes);
+    SAMD_HIP(ctx, hipMemcpyAsync(h.data(), ghist.p + passes * kRsRadix, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < passes; p++)
+      fprintf(stderr, "look-back pass %d: %u tiles, %.2f rounds per tile (max %u), %.2f idle rounds per tile\n", p, h[4 * p],
+              (double)h[4 * p + 1] / ntiles, h[4 * p + 3], (double)h[4 * p + 2] / ntiles);
   }
   *keys_out = kin;
   *pay_out = pin;
