@@ -147,10 +147,16 @@ int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit
     maxb = max16 / 256.0 * 4.0 + 64.0;
     if (maxb > 0.5 * cap) return 0;
   }
-  const int use_cap = maxb <= 0.5 * cap_small ? cap_small : cap;
+  if (ctx->opt_ablate & 0x80000)
+    fprintf(stderr, "msd_choose: samples %lld, largest bin %lld, bins in use %lld, max16 %.0f, avg16 %.0f, T %d, maxb %.0f\n",
+            (long long)samples, (long long)h[0], (long long)h[1], max16, avg16, t, maxb);
+  // The small chunk as long as the largest bucket leaves a quarter of it free: nominal spacing = capacity - largest
+  // bucket, so no chunk can outgrow its workgroup; spacings shorter than the buckets leave empty chunks, which cost
+  // next to nothing (msd_mark_empty_kernel).  C2 (buckets of 1280): 5.1 -> 4.8 ms with the small chunk.
+  const int use_cap = maxb <= 0.75 * cap_small ? cap_small : cap;
   uint32_t c = (uint32_t)use_cap - (uint32_t)maxb;
   c &= ~255u;
-  if (c < (uint32_t)use_cap / 2) c = (uint32_t)use_cap / 2;
+  if (c < 256u) c = 256u;
   *tb = end_bit - t;
   *ch = c;
   *small = use_cap == cap_small;
@@ -182,6 +188,21 @@ __global__ __launch_bounds__(kBlock) void msd_chunk_plan_kernel(const K *__restr
     if ((K)(keys[mid] >> tb) != top0) t = mid; else f = mid;
   }
   a[c] = (uint32_t)t;
+}
+
+// Chunks that hold nothing (the nominal spacing is shorter than the buckets) are taken out of the list before the
+// sort kernel runs: even a workgroup that leaves at once holds its slot for a ticket and two loads, and at two empty
+// chunks in three that was 0.3 ms on C2.  Flag = chunk holds something; exclusive scan = its place in the short list.
+struct ChunkHoldsIn {
+  const uint32_t *a;
+  __device__ __forceinline__ uint32_t operator()(int64_t i) const { return a[i] != a[i + 1] ? 1u : 0u; }
+};
+__global__ __launch_bounds__(kBlock) void msd_chunk_compact_kernel(const uint32_t *__restrict__ a, uint32_t nchunks,
+                                                                   const uint32_t *__restrict__ place, uint32_t n,
+                                                                   uint32_t *__restrict__ out) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c < nchunks && a[c] != a[c + 1]) out[place[c]] = a[c];
+  if (c == nchunks) out[place[nchunks]] = n;  // place[nchunks] = number of chunks kept (written by the host-side copy below)
 }
 
 // Addresses are padded by one slot per 32 so that blocked reads (lane stride = items per thread) stay off each
@@ -248,7 +269,8 @@ __device__ __forceinline__ unsigned long long rl_lookback(unsigned long long *__
 template <class T, class I, bool INDIRECT, int ITEMS, int DB>
 __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
     const uint64_t *__restrict__ kin, const typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *__restrict__ pin,
-    const T *__restrict__ vals_src, const uint32_t *__restrict__ chunk_a, uint32_t nchunks, int tb, int minor_bits,
+    const T *__restrict__ vals_src, const uint32_t *__restrict__ chunk_a, const uint32_t *__restrict__ nchunks_dev, int tb,
+    int minor_bits,
     I *__restrict__ col_out, T *__restrict__ vals_out, int64_t *__restrict__ row_ptr, int row_atomic,
     unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket, unsigned long long *__restrict__ merged_out,
     int *__restrict__ oversize, int *__restrict__ err, int lab) {
@@ -275,6 +297,8 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
   T *sval = reinterpret_cast<T *>(raw + kR1);
 
   const int tid = threadIdx.x;
+  const uint32_t nchunks = *nchunks_dev;  // chunks that hold something; the grid was sized before this was known
+  if (blockIdx.x >= nchunks) return;
   if (tid == 0) {
     s_chunk = atomicAdd(ticket, 1u);
     s_fail = 0;
@@ -522,25 +546,34 @@ int msd_sort_emit(futhark_context *ctx, uint64_t *keys_a, uint64_t *keys_b,
   const P *ps = nullptr;
   SAMD_TRY((radix_sort_pairs<uint64_t, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, tb, end_bit, &ks, &ps, sort_err)));
   if (ps == nullptr || ps == pay_in) return set_error(ctx, "internal: msd sort without a global pass");
-  const uint32_t nchunks = (uint32_t)cdiv(n, (int64_t)ch);
-  Tmp<uint32_t> ca(ctx);
+  const uint32_t nchunks = (uint32_t)cdiv(n, (int64_t)ch);  // nominal; the ones that hold nothing drop out below
+  Tmp<uint32_t> ca(ctx), place(ctx), cb(ctx);
   Tmp<unsigned long long> status(ctx);
   SAMD_TRY(ca.get((int64_t)nchunks + 2));
+  SAMD_TRY(place.get((int64_t)nchunks + 2));
+  SAMD_TRY(cb.get((int64_t)nchunks + 3));
   SAMD_TRY(status.get(nchunks));
-  uint32_t *ticket = ca.p + nchunks + 1;
+  uint32_t *ticket = cb.p + nchunks + 2;
   SAMD_HIP(ctx, hipMemsetAsync(ticket, 0, sizeof(uint32_t), ctx->stream));
   SAMD_HIP(ctx, hipMemsetAsync(status.p, 0, sizeof(unsigned long long) * (size_t)nchunks, ctx->stream));
   hipLaunchKernelGGL((msd_chunk_plan_kernel<uint64_t>), dim3((unsigned)cdiv((int64_t)nchunks + 1, kBlock)), dim3(kBlock), 0,
                      ctx->stream, (const uint64_t *)ks, (uint32_t)n, tb, ch, nchunks, ca.p);
   SAMD_LAUNCH_CHECK(ctx);
+  // place[c] = chunks kept before c; place[nchunks] = chunks kept
+  SAMD_TRY((device_scan<uint32_t, OpAdd, ChunkHoldsIn, true>(ctx, ChunkHoldsIn{ca.p}, nchunks, 0u, OpAdd(), place.p,
+                                                             place.p + nchunks)));
+  hipLaunchKernelGGL(msd_chunk_compact_kernel, dim3((unsigned)cdiv((int64_t)nchunks + 1, kBlock)), dim3(kBlock), 0,
+                     ctx->stream, (const uint32_t *)ca.p, nchunks, (const uint32_t *)place.p, (uint32_t)n, cb.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  const uint32_t *kept = place.p + nchunks;
   if (small)
     hipLaunchKernelGGL((rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItemsSmall, kRlDigitBits>), dim3(nchunks),
-                       dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)ca.p, nchunks, tb,
+                       dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)cb.p, kept, tb,
                        minor_bits, col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0, status.p, ticket, merged_out,
                        oversize, sort_err, (int)ctx->opt_ablate);
   else
     hipLaunchKernelGGL((rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItems, kRlDigitBits>), dim3(nchunks),
-                       dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)ca.p, nchunks, tb,
+                       dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)cb.p, kept, tb,
                        minor_bits, col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0, status.p, ticket, merged_out,
                        oversize, sort_err, (int)ctx->opt_ablate);
   SAMD_LAUNCH_CHECK(ctx);
