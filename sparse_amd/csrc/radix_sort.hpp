@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void rs_hist_all(const K *__restrict__ keys
         const int shift = begin_bit + 8 * p;
         const int nb = end_bit - shift < 8 ? end_bit - shift : 8;
         const uint32_t d = ok ? ((uint32_t)(key >> shift) & ((1u << nb) - 1u)) : 0xffffffffu;
-        const uint32_t before = wshfl_up(d, 1);
+        const uint32_t before = wave_prev_lane_dpp(d);
         const bool head = lane == 0 || d != before;
         const uint64_t hm = __ballot(head);
         if (head && ok) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin,
 #pragma unroll
   for (int k = 0; k < ITEMS; k++) {
     const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
-    const uint32_t before = wshfl_up(d, 1);
+    const uint32_t before = wave_prev_lane_dpp(d);
     const bool head = lane == 0 || d != before;
     const uint64_t hm = __ballot(head);
     if (head) {

@@ -7,6 +7,8 @@
 // order and every global access is a fully coalesced 64-lane row.
 #pragma once
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace samd {
@@ -38,8 +40,28 @@ __device__ __forceinline__ V wshfl(V v, int src) { return __shfl(v, src, 64); }
 template <class V>
 __device__ __forceinline__ V wshfl_xor(V v, int m) { return __shfl_xor(v, m, 64); }
 
+// Inclusive add-scan of one 32-bit value per lane with DPP moves (row shifts inside the rows of 16 lanes, then the
+// two row broadcasts): six VALU-speed steps.  __shfl_up goes through the LDS crossbar (ds_bpermute, ~100 cycles a
+// step), which is what the generic scan above pays; the in-LDS sort calls this once per pass and chunk.
+__device__ __forceinline__ uint32_t wave_inclusive_add_dpp(uint32_t x) {
+  // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes without a source keep `old` (0: adds nothing)
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
+// the 32-bit value of the lane below (lane 0 keeps its own): one DPP move (wave_shr:1) instead of a trip through LDS
+__device__ __forceinline__ uint32_t wave_prev_lane_dpp(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138, 0xf, 0xf, false);
+}
+
 template <class V, class Op>
 __device__ __forceinline__ V wave_inclusive_scan(V x, Op op, int lane) {
+  if constexpr (std::is_same<V, uint32_t>::value && std::is_same<Op, OpAdd>::value) return wave_inclusive_add_dpp(x);
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     V y = wshfl_up(x, d);
