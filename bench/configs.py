@@ -115,6 +115,9 @@ def main():
         byt = nnz * (vb + ib) + n * rb + n * vb + m * vb
         out.update({"spmv_ms": round(ms, 4), "spmv_GFLOPs": round(2 * nnz / ms / 1e6, 1),
                     "spmv_GBs": round(byt / ms / 1e6, 1), "spmv_frac_peak": round(byt / ms / 1e6 / PEAK, 4)})
+        if ctx.get_option("spmv_last_path") == 3:
+            out["pb_fold"] = ctx.get_option("spmv_last_pb_fold")
+            out["pb_products"] = ctx.get_option("spmv_last_pb_outputs")
         if args.compare:
             r2, c2, v2 = M.sr.coo(A)
             ref = torch.sparse_coo_tensor(torch.stack([torch.as_tensor(r2, device=dev), torch.as_tensor(c2, device=dev)]),

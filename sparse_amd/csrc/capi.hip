@@ -701,6 +701,8 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_pb_rows")) ctx->opt_spmv_pb_rows = value;
   else if (!strcmp(key, "spmv_pb_lines")) ctx->opt_spmv_pb_lines = value;
   else if (!strcmp(key, "spmv_pb_entries")) ctx->opt_spmv_pb_entries = value;
+  else if (!strcmp(key, "spmv_pb_fold")) ctx->opt_spmv_pb_fold = value;
+  else if (!strcmp(key, "spmv_pb_oround")) ctx->opt_spmv_pb_oround = value;
   else if (!strcmp(key, "spmv_2d")) ctx->opt_spmv_2d = value;
   else if (!strcmp(key, "spmv_2d_rows")) ctx->opt_spmv_2d_rows = value;
   else if (!strcmp(key, "spmv_2d_cols")) ctx->opt_spmv_2d_cols = value;
@@ -723,6 +725,9 @@ int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *k
   if (!strcmp(key, "sort_last_msd")) return ctx->last_sort_msd;
   if (!strcmp(key, "spmv_reorder")) return ctx->opt_spmv_reorder;
   if (!strcmp(key, "spmv_pb")) return ctx->opt_spmv_pb;
+  if (!strcmp(key, "spmv_pb_fold")) return ctx->opt_spmv_pb_fold;
+  if (!strcmp(key, "spmv_last_pb_fold")) return ctx->last_pb_fold;
+  if (!strcmp(key, "spmv_last_pb_outputs")) return ctx->last_pb_outputs;
   if (!strcmp(key, "spmv_2d")) return ctx->opt_spmv_2d;
   if (!strcmp(key, "num_cu")) return ctx->num_cu;
   if (!strcmp(key, "spmv_last_path")) return ctx->last_spmv_path;

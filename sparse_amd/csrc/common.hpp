@@ -121,6 +121,10 @@ struct futhark_context {
   int64_t opt_spmv_pb = 0;  // two-pass SpMV (spmv_pb.hpp), 0 large skewed gather-bound records of 4-byte values, 1 also flat popularity, 2 always (tests), -1 never
   int64_t opt_spmv_pb_rows = 0, opt_spmv_pb_lines = 0, opt_spmv_pb_entries = 0;  // test overrides: rows per panel,
                                                                                  // 32-column lines per block, entries per panel
+  int64_t opt_spmv_pb_fold = 0;  // two-pass SpMV, products of one row inside one piece summed in pass 1: 0 when it shortens the product stream by >= 15 %, 1 always, -1 never
+  int64_t opt_spmv_pb_oround = 0;  // lab: folded layout, alignment of a piece's outputs in products (0 = kPbOutRound)
+  int64_t last_pb_fold = 0;      // 1 if the last two-pass product ran on a folded layout; last_pb_outputs: products it wrote (pads included)
+  int64_t last_pb_outputs = 0;
   int64_t opt_spmv_2d = 0;  // 2-D blocked SpMV (spmv_2d.hpp): 0 large skewed records of 4-byte values, 2 always (tests), -1 never
   int64_t opt_spmv_2d_rows = 0, opt_spmv_2d_cols = 0, opt_spmv_2d_entries = 0, opt_spmv_2d_dense = 0;  // test / lab overrides
   int64_t opt_sort_indirect = 0;  // lab: 1 = assembly sorts 8-byte values by 4-byte source index and gathers them at the end
@@ -275,6 +279,8 @@ struct CsrBody {
   mutable T *cblk_val = nullptr;
   // two-pass copy for gather-bound SpMV on power-law records (spmv_pb.hpp); built lazily
   mutable int pb_state = 0;  // 0 undecided, 1 active, -1 rejected
+  mutable int pb_fold = 0;   // 1: folded layout (pb_col16 bit 15 = first entry of a run, pb_dgroup = first output of every group of 32 entries)
+  mutable int64_t pb_outputs = 0;  // products pass 1 writes (pads included)
   mutable int64_t pb_np = 0, pb_nb = 0, pb_w = 0, pb_nl = 0;  // panels, column blocks, columns per block, 32-column lines
   mutable int64_t *pb_panel_row = nullptr;   // [np + 1] first row of every panel
   mutable int64_t *pb_piece_ptr = nullptr;   // [np * nb + 1] start of every piece, panel-major

@@ -58,6 +58,7 @@ constexpr int64_t kPbMinBytes = 16 << 20;            // x at least this large (R
                                                     // scale 20 0.21 / 0.15, 21 0.264 / 0.259, 22 0.47 / 0.51, 23 0.81 / 1.01, 24 1.62 / 2.08)
 constexpr int kPbFoldRows = 64;                     // a panel of fewer rows than this keeps its entries sorted by row: pass 2 folds runs
 constexpr int kPbFoldFlag = 0x8000;                 // row16 bit that says so
+constexpr int kPbOutRound = 32;                     // folded layout: a piece's outputs start at a multiple of this many products (C3, 1 / 8 / 16 / 32: pass 1 0.714 / 0.707 / 0.694 / 0.687 ms, pass 2 0.266 / 0.265 / 0.267 / 0.260)
 constexpr int64_t kPbMinPiece = 128;               // auto mode: mean entries per piece below this -> not worth it
 
 // Popularity of the 32-column lines from every stride-th entry: the ranking only has to deal the lines to the
@@ -309,6 +310,12 @@ __device__ __forceinline__ V pb_wave_sum(V v) {
   return v;
 }
 
+// pads of the panel-major stream: rows kRows .. kRows + 31 (the trash slots behind the slice), by position
+__global__ __launch_bounds__(kBlock) void pb_fill_trash_kernel(uint16_t *__restrict__ row16, int64_t n, int base) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) row16[i] = (uint16_t)(base + (int)(i & 31));
+}
+
 template <class T, int U>
 __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__restrict__ panel_ptr,
                                                               const int64_t *__restrict__ panel_row,
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__r
                                                               int lab, int fold_max) {
   typedef typename PbAcc<T>::type acc_t;
   constexpr int kTrash = PbSlice<T>::kRows;
-  __shared__ acc_t ys[kTrash + 1];
+  __shared__ acc_t ys[kTrash + 32];  // 32 trash slots: the pads of one instruction land in different bank pairs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t p = blockIdx.x;
   const int64_t r0 = panel_row[p];
@@ -376,6 +383,480 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__r
   }
   __syncthreads();
   for (int j2 = tid; j2 < rows; j2 += kPbThreads) y[r0 + j2] = (T)ys[j2];
+}
+
+// ------------------------------------------------------------------------------------------------ folded layout
+// On a power-law matrix a heavy row has many entries in one column block: their products belong to one element of
+// y, and pass 1 can add them up before anything is written.  C3: a row of 1300 entries meets each of the 512 blocks
+// 2.5 times, the 13 000 heaviest rows (28 % of the entries) 8 times and more; the product stream shrinks to about
+// half, which takes 10 bytes per dropped product off the 16 the two passes move per entry.
+// Layout: a piece's entries are grouped in RUNS (one row each), a run's entries are neighbours in the block-major
+// stream, bit 15 of col16 marks a run's first entry and every position that is a multiple of 32 starts a new run
+// (so a run never leaves the 32 lanes that hold its group).  Pass 1 forms the products, adds each run up inside the
+// wavefront (segmented scan over DPP moves, skipped when the instruction holds no run longer than one entry) and the
+// last lane of a run stores the sum at pb_dgroup[group] + (runs before it in the group): the outputs of a piece
+// are contiguous in the panel-major stream, in the order of its runs.  That order is the bank-pair deal of the
+// plain layout applied to runs, so pass 2 (the same kernel, nothing to fold any more) still sees each bank pair
+// about once per instruction.  Pads: the first pad of a piece starts a run whose row is the trash slot.
+template <int CTRL, int ROWMASK, class T>
+__device__ __forceinline__ T pb_dpp0(T v) {  // lanes without a source (or outside ROWMASK) read 0
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+  } else {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, ROWMASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, ROWMASK, 0xf, false);
+    return __builtin_bit_cast(T, ((uint64_t)hi << 32) | lo);
+  }
+}
+
+// Per-lane constants of the run arithmetic.  A run never leaves its 32-lane half (positions that are multiples of 32
+// start a run), so every lane works on its half's 32 bits of the wavefront's masks.
+struct PbLane {
+  int lane, l5;
+  bool hi;
+  uint32_t upto, bit, under;  // bits 0..l5, bit l5, bits 0..l5-1
+  __device__ __forceinline__ explicit PbLane(int ln) : lane(ln), l5(ln & 31), hi(ln >= 32) {
+    bit = 1u << l5;
+    under = bit - 1u;
+    upto = under | bit;
+  }
+  __device__ __forceinline__ uint32_t half(unsigned long long m) const { return hi ? (uint32_t)(m >> 32) : (uint32_t)m; }
+};
+
+// heads: lanes that start a run (lanes 0 and 32 among them).  Returns in a run's last lane the sum of the run.
+template <class T>
+__device__ __forceinline__ T pb_run_sum(T p, unsigned long long heads, const PbLane &L) {
+  if (heads == ~0ull) return p;  // every run is one entry (the thin part of the matrix)
+  const int dist = L.l5 - 31 + __builtin_clz(L.half(heads) & L.upto);  // distance to the run's first lane
+  {
+    const T t = pb_dpp0<0x111, 0xf>(p);  // row_shr:1
+    if (dist >= 1) p = (T)(p + t);
+  }
+  if (__ballot(dist >= 2) != 0ull) {
+    {
+      const T t = pb_dpp0<0x112, 0xf>(p);
+      if (dist >= 2) p = (T)(p + t);
+    }
+    if (__ballot(dist >= 4) != 0ull) {
+      {
+        const T t = pb_dpp0<0x114, 0xf>(p);
+        if (dist >= 4) p = (T)(p + t);
+      }
+      {
+        const T t = pb_dpp0<0x118, 0xf>(p);
+        if (dist >= 8) p = (T)(p + t);
+      }
+    }
+  }
+  // a run that began in the 16 lanes before this row: lane 15 of that row holds its part there
+  {
+    const T t = pb_dpp0<0x142, 0xa>(p);  // row_bcast:15 into rows 1 and 3
+    if (dist > (L.lane & 15)) p = (T)(p + t);
+  }
+  return p;
+}
+
+__device__ __forceinline__ int pb_rank_in_half(unsigned long long mask, int lane) {  // set bits below the lane inside its 32-lane half
+  const PbLane L(lane);
+  return __popc(L.half(mask) & L.under);
+}
+
+template <class P>
+__device__ __forceinline__ P *pb_uniform_ptr(P *p) {  // p is the same in every lane: keep it in scalar registers
+  const uint64_t u = (uint64_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  typedef __attribute__((address_space(1))) P G;  // global memory: an integer cast alone would leave a generic (flat) pointer
+  return (P *)(G *)(((uint64_t)hi << 32) | lo);
+}
+
+// LAB (kernel lab, results wrong): 1 no store, 2 no LDS gather, 3 plain store, 4 no run sums
+template <class T, int U, int LAB>
+__global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__restrict__ block_ptr,
+                                                               const uint16_t *__restrict__ col16,
+                                                               const T *__restrict__ pval, const T *__restrict__ xperm,
+                                                               const uint32_t *__restrict__ uout,
+                                                               T *__restrict__ prod, int w) {
+  __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
+  const int64_t b = blockIdx.x;
+  {
+    constexpr int PER = 16 / (int)sizeof(T);
+    const raw16 *src = reinterpret_cast<const raw16 *>(xperm + b * (int64_t)w);
+    for (int j = threadIdx.x; j < w / PER; j += kPbThreads) reinterpret_cast<raw16 *>(xs)[j] = src[j];
+  }
+  constexpr int64_t kStep = (int64_t)kPbThreads * U;
+  constexpr int kChunk = 64 * U;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const PbLane L(lane);
+  const int64_t s0 = block_ptr[b], e0 = block_ptr[b + 1];
+  const int64_t per = cdiv_dev(cdiv_dev(e0 - s0, kStep), (int64_t)gridDim.y) * kStep;
+  const int64_t s = s0 + (int64_t)blockIdx.y * per;
+  const int64_t e = s + per < e0 ? s + per : e0;
+  __syncthreads();
+  // A wavefront takes 64 U consecutive entries per step: runs are neighbouring lanes.  s, e and every step are
+  // multiples of 32, so lanes 0 and 32 always sit on a forced run start.  The next step's entries are requested
+  // before the current one's runs are summed (the sums are ~30 vector instructions per 64 entries).
+  // (32-bit registers for the 16-bit columns: packed pairs would make each load wait for its neighbour; base
+  // addresses pinned to scalar registers: otherwise the compiler folds the lane offset into a loop-invariant 64-bit
+  // vector base and spends four vector instructions per load on the address)
+  auto load = [&](int64_t cs, uint32_t (&c)[U], T (&v)[U], uint32_t (&g)[U]) {  // a whole step
+    const uint16_t *cp = pb_uniform_ptr(col16 + cs);  // cs is the same in every lane
+    const T *vp = pb_uniform_ptr(pval + cs);
+    const uint32_t *gp = pb_uniform_ptr(uout + (cs >> 5));
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      c[u] = (uint32_t)ntload(cp + (unsigned)(u * 64 + lane));
+      v[u] = ntload(vp + (unsigned)(u * 64 + lane));
+      g[u] = gp[(unsigned)(u * 2 + (lane >> 5))];
+    }
+  };
+  auto work = [&](const uint32_t (&c)[U], const T (&v)[U], const uint32_t (&g)[U], int n) {  // n: entries of the step
+    T pr[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) pr[u] = LAB == 2 ? v[u] : (T)(v[u] * xs[c[u] & 0x7fff]);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const bool ok = u * 64 + lane < n;
+      const unsigned long long heads = __ballot(!ok || (c[u] & 0x8000) != 0);
+      const T sum = LAB == 4 ? pr[u] : pb_run_sum<T>(pr[u], heads, L);
+      const uint32_t tails = L.half(heads >> 1) | (L.hi ? 0x80000000u : 0u);  // bit 31 of the low half: lane 32 starts a run
+      if (ok && (tails & L.bit) != 0) {
+        T *d = prod + ((int64_t)g[u] + __popc(tails & L.under));
+        if (LAB == 3) *d = sum;
+        else if (LAB != 1 || sum == (T)12345) __builtin_nontemporal_store(sum, d);
+      }
+    }
+  };
+  int64_t cs = s + (int64_t)wave * kChunk;
+  cs = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cs >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
+  uint32_t ca[U], cb[U], ga[U], gb[U];
+  T va[U], vb[U];
+  // (the next step is requested unconditionally -- when there is none, the current one again, which is in cache:
+  // behind a branch the compiler cannot tell which requests are outstanding where the paths join, and makes the
+  // sums of this step wait for half of the next step's loads)
+  bool more = cs + kChunk <= e;
+  if (more) load(cs, ca, va, ga);
+  while (more) {
+    const int64_t c1 = cs + kStep;
+    const bool more1 = c1 + kChunk <= e;
+    load(more1 ? c1 : cs, cb, vb, gb);
+    work(ca, va, ga, kChunk);
+    cs = c1;
+    if (!more1) break;
+    const int64_t c2 = c1 + kStep;
+    more = c2 + kChunk <= e;
+    load(more ? c2 : c1, ca, va, ga);
+    work(cb, vb, gb, kChunk);
+    cs = c2;
+  }
+  if (cs < e) {  // the range's last, partial step: clamped offsets (never a predicated load, see pb_pass1_kernel)
+    const int n = (int)(e - cs);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int o = u * 64 + lane;
+      const int64_t ic = cs + (o < n ? o : n - 1);
+      ca[u] = (uint32_t)ntload(&col16[ic]);
+      va[u] = ntload(&pval[ic]);
+      ga[u] = uout[ic >> 5];
+    }
+    work(ca, va, ga, n);
+  }
+}
+
+// ---- building the folded layout (once per record) from the entries sorted by (piece, row mod 32, row, column)
+__global__ __launch_bounds__(kBlock) void pbf_rows_kernel(const int64_t *__restrict__ row_ptr, int64_t nnz,
+                                                          const int64_t *__restrict__ tile_lb, int64_t tile,
+                                                          const int64_t *__restrict__ panel_row, int64_t np,
+                                                          const uint32_t *__restrict__ sorted_keys,
+                                                          const uint32_t *__restrict__ perm, uint16_t *__restrict__ rr) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nnz) return;
+  const int64_t src = perm ? (int64_t)perm[i] : i;
+  const int64_t p = (int64_t)(sorted_keys[i] >> 5) % np;
+  rr[i] = (uint16_t)(find_row(row_ptr, tile_lb, tile, src) - panel_row[p]);
+}
+
+struct PbRunHeadIn {  // 1 where sorted entry i starts a run: first of its piece or another row than its predecessor
+  const uint32_t *keys;
+  const uint16_t *rr;
+  __device__ __forceinline__ uint32_t operator()(int64_t i) const {
+    return (i == 0 || (keys[i] >> 5) != (keys[i - 1] >> 5) || rr[i] != rr[i - 1]) ? 1u : 0u;
+  }
+};
+
+struct PbU32AsI64In {
+  const uint32_t *p;
+  __device__ __forceinline__ int64_t operator()(int64_t i) const { return (int64_t)p[i]; }
+};
+
+// run_start[j] = sorted position of run j's first entry, run_start[runs] = nnz
+__global__ __launch_bounds__(kBlock) void pbf_runstart_kernel(PbRunHeadIn head, const uint32_t *__restrict__ hscan,
+                                                              int64_t nnz, uint32_t *__restrict__ run_start) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nnz) return;
+  if (head(i)) run_start[hscan[i] - 1] = (uint32_t)i;
+  if (i == nnz - 1) run_start[hscan[i]] = (uint32_t)nnz;
+}
+
+// piece_run[k] = runs in front of piece k (k = 0 .. pieces); slots[k] = places of the piece in the dealt order:
+// its runs rounded up to whole groups of 32, plus one place that carries the piece's padding
+__global__ __launch_bounds__(kBlock) void pbf_piece_runs_kernel(const int64_t *__restrict__ piece_ptr,
+                                                                const uint32_t *__restrict__ hscan, int64_t pieces,
+                                                                uint32_t *__restrict__ piece_run,
+                                                                int64_t *__restrict__ slots) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k > pieces) return;
+  const int64_t a = piece_ptr[k];
+  const uint32_t ra = a > 0 ? hscan[a - 1] : 0u;
+  piece_run[k] = ra;
+  if (k == pieces) { slots[k] = 0; return; }
+  const int64_t b = piece_ptr[k + 1];
+  const uint32_t rb = b > 0 ? hscan[b - 1] : 0u;
+  slots[k] = (int64_t)(((rb - ra) + 31u) & ~31u) + 1;
+}
+
+// run j -> its place in the dealt order of its piece (the deal of pb_build_kernel, applied to runs); len[place] =
+// entries of the run; the piece's extra place gets its padding
+__global__ __launch_bounds__(kBlock) void pbf_slot_kernel(const uint32_t *__restrict__ sorted_keys,
+                                                          const uint32_t *__restrict__ run_start, int64_t runs,
+                                                          const uint32_t *__restrict__ piece_run,
+                                                          const int64_t *__restrict__ sbase,
+                                                          const int64_t *__restrict__ piece_ptr,
+                                                          uint32_t *__restrict__ len, uint32_t *__restrict__ run_slot) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= runs) return;
+  const uint32_t i0 = run_start[j];
+  const int64_t k = (int64_t)(sorted_keys[i0] >> 5);
+  const int64_t jl = j - (int64_t)piece_run[k], N = (int64_t)piece_run[k + 1] - (int64_t)piece_run[k];
+  const int64_t G = (N + 31) >> 5, sl = jl / G;
+  const int64_t slot = sbase[k] + (jl % G) * 32 + ((sl & 1) * 16 + (sl >> 1));
+  len[slot] = run_start[j + 1] - i0;
+  run_slot[j] = (uint32_t)slot;
+  if (jl == 0) len[sbase[k] + G * 32] = (uint32_t)((-(piece_ptr[k + 1] - piece_ptr[k])) & 31);
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void pbf_place_kernel(const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                           int64_t nnz, const uint32_t *__restrict__ rank_of_line,
+                                                           int64_t nb, const uint32_t *__restrict__ perm,
+                                                           const uint32_t *__restrict__ hscan,
+                                                           const uint32_t *__restrict__ run_start,
+                                                           const uint32_t *__restrict__ run_slot,
+                                                           const int64_t *__restrict__ spos, const uint16_t *__restrict__ rr,
+                                                           uint16_t *__restrict__ col16, T *__restrict__ pval,
+                                                           uint16_t *__restrict__ rowt) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nnz) return;
+  const int64_t src = perm ? (int64_t)perm[i] : i;
+  const uint32_t j = hscan[i] - 1;
+  const uint32_t i0 = run_start[j];
+  const int64_t pos = spos[run_slot[j]] + (i - (int64_t)i0);
+  const int32_t c = col[src];
+  const int64_t q = rank_of_line[c / kPbLine];
+  const bool head = i == (int64_t)i0 || (pos & 31) == 0;
+  col16[pos] = (uint16_t)(((q / nb) * kPbLine + (c % kPbLine)) | (head ? 0x8000 : 0));
+  pval[pos] = val[src];
+  rowt[pos] = rr[i];
+}
+
+// per piece: its first pad starts the trash run; heads per group counted afterwards
+__global__ __launch_bounds__(kBlock) void pbf_padhead_kernel(const int64_t *__restrict__ piece_ptr,
+                                                             const uint32_t *__restrict__ piece_run,
+                                                             const int64_t *__restrict__ sbase,
+                                                             const int64_t *__restrict__ spos, int64_t pieces,
+                                                             uint16_t *__restrict__ col16) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= pieces) return;
+  if (((piece_ptr[k + 1] - piece_ptr[k]) & 31) == 0) return;
+  const int64_t N = (int64_t)piece_run[k + 1] - (int64_t)piece_run[k], G = (N + 31) >> 5;
+  col16[spos[sbase[k] + G * 32]] = 0x8000;
+}
+
+__global__ __launch_bounds__(kBlock) void pbf_group_heads_kernel(const uint16_t *__restrict__ col16, int64_t groups,
+                                                                 uint32_t *__restrict__ cnt) {
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g > groups) return;
+  uint32_t n = 0;
+  if (g < groups) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(col16 + g * 32);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint4 w = p[q];
+      n += __popc(w.x & 0x80008000u) + __popc(w.y & 0x80008000u) + __popc(w.z & 0x80008000u) + __popc(w.w & 0x80008000u);
+    }
+  }
+  cnt[g] = n;  // element `groups` = 0: the exclusive scan leaves the total there
+}
+
+// outputs of every piece, rounded up (pass 1's stores like a piece to start on a line; the pads cost pass 2 nothing
+// but their bytes since each of an instruction's pads has a trash slot of its own: with one shared slot they took
+// 16 turns on it and pass 2 ran 0.325 ms instead of 0.260), written where the panel-major scan wants them
+__global__ __launch_bounds__(kBlock) void pbf_osz_kernel(const int64_t *__restrict__ sbase, const int64_t *__restrict__ spos,
+                                                         const uint32_t *__restrict__ hx, int64_t pieces, int64_t np,
+                                                         int64_t nb, uint32_t round, int64_t *__restrict__ poff) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k > pieces) return;
+  if (k == pieces) { poff[k] = 0; return; }
+  const int64_t g0 = spos[sbase[k]] >> 5, g1 = spos[sbase[k + 1]] >> 5;
+  const int64_t b = k / np, p = k - b * np;
+  poff[p * nb + b] = (int64_t)((hx[g1] - hx[g0] + round - 1u) / round * round);
+}
+
+__global__ __launch_bounds__(kBlock) void pbf_uout_kernel(const int64_t *__restrict__ sbase, const int64_t *__restrict__ spos,
+                                                          const uint32_t *__restrict__ hx, const int64_t *__restrict__ poff,
+                                                          int64_t pieces, int64_t np, int64_t nb,
+                                                          uint32_t *__restrict__ uout) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= pieces) return;
+  const int64_t g0 = spos[sbase[k]] >> 5, g1 = spos[sbase[k + 1]] >> 5;
+  const int64_t b = k / np, p = k - b * np;
+  const int64_t base = poff[p * nb + b];
+  const uint32_t h0 = hx[g0];
+  for (int64_t g = g0; g < g1; g++) uout[g] = (uint32_t)(base + (int64_t)(hx[g] - h0));
+}
+
+// the row of every output, where pass 2 streams it
+__global__ __launch_bounds__(kBlock) void pbf_rows_out_kernel(const uint16_t *__restrict__ col16,
+                                                              const uint16_t *__restrict__ rowt, int64_t ptotal,
+                                                              const uint32_t *__restrict__ uout,
+                                                              uint16_t *__restrict__ row16) {
+  const int64_t pos = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // ptotal is a multiple of 32, blocks of 256
+  const bool ok = pos < ptotal;
+  const bool head = ok && (col16[pos] & 0x8000) != 0;
+  const unsigned long long heads = __ballot(head);
+  if (head) row16[(int64_t)uout[pos >> 5] + pb_rank_in_half(heads, (int)(threadIdx.x & 63))] = rowt[pos];
+}
+
+__global__ __launch_bounds__(kBlock) void pbf_bounds_kernel(const int64_t *__restrict__ sbase, const int64_t *__restrict__ spos,
+                                                            const int64_t *__restrict__ poff, int64_t np, int64_t nb,
+                                                            int64_t *__restrict__ bounds) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i <= nb) bounds[i] = spos[sbase[i * np]];
+  else if (i <= nb + 1 + np) bounds[i] = poff[(i - nb - 1) * nb];
+}
+
+// Builds the folded layout from the sorted entries.  *done = false (and nothing kept) when folding would not shorten
+// the product stream enough, or the sizes leave the 32-bit indices.
+template <class T>
+int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, const uint32_t *eperm,
+              const int64_t *piece_ptr, const int64_t *panel_row, const uint32_t *rank_of_line, int64_t nb, int64_t np,
+              int64_t pieces, bool *done) {
+  *done = false;
+  const int64_t nnz = a->nnz;
+  const unsigned egrid = (unsigned)cdiv(nnz, kBlock), pgrid = (unsigned)cdiv(pieces + 1, kBlock);
+  Tmp<uint16_t> rr(ctx);
+  Tmp<uint32_t> hscan(ctx);
+  SAMD_TRY(rr.get(nnz));
+  SAMD_TRY(hscan.get(nnz));
+  hipLaunchKernelGGL(pbf_rows_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, (const int64_t *)a->row_ptr, nnz,
+                     (const int64_t *)a->tile_lb, a->tile, panel_row, np, eks, eperm, rr.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  const PbRunHeadIn head{eks, rr.p};
+  uint32_t *d_runs = reinterpret_cast<uint32_t *>(ctx->d_small + 4);
+  SAMD_TRY((device_scan<uint32_t, OpAdd, PbRunHeadIn, false>(ctx, head, nnz, 0u, OpAdd(), hscan.p, d_runs)));
+  int64_t small[8];
+  SAMD_TRY(read_small(ctx, ctx->d_small, 5, small));
+  const int64_t runs = (int64_t)(uint32_t)(small[4] & 0xffffffff);
+  if (ctx->logging) fprintf(stderr, "[sparse_amd] two-pass SpMV: %lld runs for %lld entries\n", (long long)runs, (long long)nnz);
+  if (ctx->opt_spmv_pb_fold <= 0 && (double)runs > 0.85 * (double)nnz) return 0;  // not worth the fold arithmetic
+  if (runs + 33 * pieces >= (int64_t)0xffffff00LL) return 0;                      // 32-bit places and outputs
+  Tmp<uint32_t> run_start(ctx), piece_run(ctx), run_slot(ctx), len(ctx);
+  Tmp<int64_t> sbase(ctx), spos(ctx);
+  SAMD_TRY(run_start.get(runs + 1));
+  SAMD_TRY(piece_run.get(pieces + 1));
+  SAMD_TRY(run_slot.get(runs));
+  SAMD_TRY(sbase.get(pieces + 1));
+  hipLaunchKernelGGL(pbf_runstart_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, head, (const uint32_t *)hscan.p, nnz,
+                     run_start.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(pbf_piece_runs_kernel, dim3(pgrid), dim3(kBlock), 0, ctx->stream, piece_ptr, (const uint32_t *)hscan.p,
+                     pieces, piece_run.p, sbase.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  SAMD_TRY((device_scan<int64_t, OpAdd, PtrIn<int64_t>, true>(ctx, PtrIn<int64_t>{sbase.p}, pieces + 1, (int64_t)0, OpAdd(),
+                                                               sbase.p, (int64_t *)nullptr)));
+  SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small, sbase.p + pieces, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, small));
+  const int64_t places = small[0];  // all pieces' places in the dealt order
+  SAMD_TRY(len.get(places + 1));
+  SAMD_TRY(spos.get(places + 1));
+  SAMD_HIP(ctx, hipMemsetAsync(len.p, 0, sizeof(uint32_t) * (size_t)(places + 1), ctx->stream));
+  hipLaunchKernelGGL(pbf_slot_kernel, dim3((unsigned)cdiv(runs, kBlock)), dim3(kBlock), 0, ctx->stream, eks,
+                     (const uint32_t *)run_start.p, runs, (const uint32_t *)piece_run.p, (const int64_t *)sbase.p, piece_ptr,
+                     len.p, run_slot.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  SAMD_TRY((device_scan<int64_t, OpAdd, PbU32AsI64In, true>(ctx, PbU32AsI64In{len.p}, places + 1, (int64_t)0, OpAdd(), spos.p,
+                                                             (int64_t *)nullptr)));
+  SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small, spos.p + places, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, small));
+  const int64_t ptotal = small[0];  // entries of the block-major layout, pads included: a multiple of 32
+  const int64_t groups = ptotal >> 5;
+  if ((ptotal & 31) != 0) return set_error(ctx, "internal: folded two-pass layout is not made of whole groups");
+  Tmp<uint16_t> col16(ctx), rowt(ctx), row16(ctx);
+  Tmp<T> pval(ctx), prod(ctx), xperm(ctx);
+  Tmp<uint32_t> hx(ctx), uout(ctx);
+  Tmp<int64_t> poff(ctx), bounds(ctx);
+  SAMD_TRY(col16.get(ptotal));
+  SAMD_TRY(rowt.get(ptotal));
+  SAMD_TRY(pval.get(ptotal));
+  SAMD_TRY(hx.get(groups + 1));
+  SAMD_TRY(uout.get(groups));
+  SAMD_TRY(poff.get(pieces + 1));
+  SAMD_TRY(bounds.get(nb + 1 + np + 1));
+  SAMD_HIP(ctx, hipMemsetAsync(col16.p, 0, sizeof(uint16_t) * (size_t)ptotal, ctx->stream));
+  SAMD_HIP(ctx, hipMemsetAsync(pval.p, 0, sizeof(T) * (size_t)ptotal, ctx->stream));
+  SAMD_HIP(ctx, hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(rowt.p), (unsigned short)PbSlice<T>::kRows, (size_t)ptotal,
+                                  ctx->stream));
+  hipLaunchKernelGGL((pbf_place_kernel<T>), dim3(egrid), dim3(kBlock), 0, ctx->stream, (const int32_t *)a->col32,
+                     (const T *)a->vals, nnz, rank_of_line, nb, eperm, (const uint32_t *)hscan.p, (const uint32_t *)run_start.p,
+                     (const uint32_t *)run_slot.p, (const int64_t *)spos.p, (const uint16_t *)rr.p, col16.p, pval.p, rowt.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(pbf_padhead_kernel, dim3(pgrid), dim3(kBlock), 0, ctx->stream, piece_ptr, (const uint32_t *)piece_run.p,
+                     (const int64_t *)sbase.p, (const int64_t *)spos.p, pieces, col16.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(pbf_group_heads_kernel, dim3((unsigned)cdiv(groups + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     (const uint16_t *)col16.p, groups, hx.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  SAMD_TRY((device_scan<uint32_t, OpAdd, PtrIn<uint32_t>, true>(ctx, PtrIn<uint32_t>{hx.p}, groups + 1, 0u, OpAdd(), hx.p,
+                                                                 (uint32_t *)nullptr)));
+  hipLaunchKernelGGL(pbf_osz_kernel, dim3(pgrid), dim3(kBlock), 0, ctx->stream, (const int64_t *)sbase.p, (const int64_t *)spos.p,
+                     (const uint32_t *)hx.p, pieces, np, nb,
+                     (uint32_t)(ctx->opt_spmv_pb_oround > 0 ? ctx->opt_spmv_pb_oround : kPbOutRound), poff.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  SAMD_TRY((device_scan<int64_t, OpAdd, PtrIn<int64_t>, true>(ctx, PtrIn<int64_t>{poff.p}, pieces + 1, (int64_t)0, OpAdd(),
+                                                               poff.p, (int64_t *)nullptr)));
+  SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small, poff.p + pieces, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, small));
+  const int64_t ototal = small[0];  // outputs
+  if (ototal >= (int64_t)0xffffff00LL) return 0;
+  SAMD_TRY(row16.get(ototal));
+  hipLaunchKernelGGL(pb_fill_trash_kernel, dim3((unsigned)cdiv(ototal, kBlock)), dim3(kBlock), 0, ctx->stream, row16.p, ototal,
+                     (int)PbSlice<T>::kRows);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(pbf_uout_kernel, dim3((unsigned)cdiv(pieces, kBlock)), dim3(kBlock), 0, ctx->stream, (const int64_t *)sbase.p,
+                     (const int64_t *)spos.p, (const uint32_t *)hx.p, (const int64_t *)poff.p, pieces, np, nb, uout.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(pbf_rows_out_kernel, dim3((unsigned)cdiv(ptotal, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     (const uint16_t *)col16.p, (const uint16_t *)rowt.p, ptotal, (const uint32_t *)uout.p, row16.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(pbf_bounds_kernel, dim3((unsigned)cdiv(nb + 1 + np + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     (const int64_t *)sbase.p, (const int64_t *)spos.p, (const int64_t *)poff.p, np, nb, bounds.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  SAMD_TRY(prod.get(ototal));
+  SAMD_HIP(ctx, hipMemsetAsync(prod.p, 0, sizeof(T) * (size_t)ototal, ctx->stream));  // output pads are read by pass 2 (into the trash slot)
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, small));  // orders the temporaries' release after their use
+  a->pb_piece_ptr = bounds.release();
+  a->pb_dgroup = uout.release();
+  a->pb_col16 = col16.release();
+  a->pb_row16 = row16.release();
+  a->pb_val = pval.release();
+  a->pb_prod = prod.release();
+  a->pb_fold = 1;
+  a->pb_outputs = ototal;
+  if (ctx->logging) fprintf(stderr, "[sparse_amd] two-pass SpMV, folded: %lld entries (padded %lld) -> %lld products\n",
+                            (long long)nnz, (long long)ptotal, (long long)ototal);
+  *done = true;
+  return 0;
 }
 
 // Decides and, if worthwhile, builds the piece copy.  One-time host synchronisations.
@@ -508,6 +989,16 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
     hipLaunchKernelGGL(pb_piece_ptr_kernel, dim3((unsigned)cdiv(pieces + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                        (const uint32_t *)eks, a->nnz, pieces, piece_ptr.p, 5);
     SAMD_LAUNCH_CHECK(ctx);
+    bool folded = false;
+    {
+      int64_t sflag[3];
+      SAMD_TRY(read_small(ctx, ctx->d_small, 3, sflag));
+      if ((int)(sflag[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
+    }
+    if (ctx->opt_spmv_pb_fold >= 0)
+      SAMD_TRY(pbf_build<T>(ctx, a, eks, eperm, (const int64_t *)piece_ptr.p, (const int64_t *)panel_row.p,
+                            (const uint32_t *)rank_of_line.p, nb, np, pieces, &folded));
+    if (!folded) {
     // ---- both padded layouts: every piece rounded up to a multiple of 32 entries
     Tmp<int64_t> boff(ctx), poff(ctx);
     SAMD_TRY(boff.get(pieces + 1));
@@ -533,8 +1024,9 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
     SAMD_TRY(bounds.get(nb + 1 + np + 1));
     SAMD_HIP(ctx, hipMemsetAsync(col16.p, 0, sizeof(uint16_t) * (size_t)ptotal, ctx->stream));
     SAMD_HIP(ctx, hipMemsetAsync(pval.p, 0, sizeof(T) * (size_t)ptotal, ctx->stream));
-    SAMD_HIP(ctx, hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(row16.p), (unsigned short)PbSlice<T>::kRows,
-                                    (size_t)ptotal, ctx->stream));  // pads: the trash slot behind the slice
+    hipLaunchKernelGGL(pb_fill_trash_kernel, dim3((unsigned)cdiv(ptotal, kBlock)), dim3(kBlock), 0, ctx->stream, row16.p, ptotal,
+                       (int)PbSlice<T>::kRows);  // pads: the trash slots behind the slice
+    SAMD_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL((pb_build_kernel<T>), dim3(egrid), dim3(kBlock), 0, ctx->stream, (const int64_t *)a->row_ptr,
                        (const int32_t *)a->col32, (const T *)a->vals, a->nnz, (const int64_t *)a->tile_lb, a->tile,
                        (const int64_t *)panel_row.p, (const uint32_t *)rank_of_line.p, nb, np, (const uint32_t *)eks, eperm,
@@ -549,21 +1041,25 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
                        (const int64_t *)boff.p, (const int64_t *)poff.p, np, nb, bounds.p);
     SAMD_LAUNCH_CHECK(ctx);
     SAMD_TRY(read_small(ctx, ctx->d_small, 1, flag));  // orders the temporaries' release after their use
+    }
   }
-  SAMD_TRY(prod.get(ptotal));
+  if (a->pb_fold == 0) SAMD_TRY(prod.get(ptotal));
   SAMD_TRY(xperm.get(nb * w));
   a->pb_np = np;
   a->pb_nb = nb;
   a->pb_w = w;
   a->pb_nl = nl;
   a->pb_panel_row = panel_row.release();
-  a->pb_piece_ptr = bounds.release();  // [nb + 1] block ranges (block-major layout), then [np + 1] panel ranges (panel-major)
-  a->pb_dgroup = dgroup.release();
+  if (a->pb_fold == 0) {
+    a->pb_piece_ptr = bounds.release();  // [nb + 1] block ranges (block-major layout), then [np + 1] panel ranges (panel-major)
+    a->pb_dgroup = dgroup.release();
+    a->pb_col16 = col16.release();
+    a->pb_row16 = row16.release();
+    a->pb_val = pval.release();
+    a->pb_prod = prod.release();
+    a->pb_outputs = ptotal;
+  }
   a->pb_line_of_rank = line_of_rank.release();
-  a->pb_col16 = col16.release();
-  a->pb_row16 = row16.release();
-  a->pb_val = pval.release();
-  a->pb_prod = prod.release();
   a->pb_x = xperm.release();
   a->pb_state = 1;
   if (ctx->logging) fprintf(stderr, "[sparse_amd] two-pass SpMV: %lld panels x %lld blocks of %lld columns, %.0f entries per piece\n",
@@ -580,15 +1076,31 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
   int64_t split = cdiv((int64_t)ctx->num_cu * 4, a->pb_nb);
   if (split < 1) split = 1;
   if (split > 65535) split = 65535;
-  hipLaunchKernelGGL((pb_pass1_kernel<T, 8>), dim3((unsigned)a->pb_nb, (unsigned)split), dim3(kPbThreads), 0, ctx->stream,
-                     (const int64_t *)a->pb_piece_ptr, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,
-                     (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w,
-                     (int)((ctx->opt_ablate >> 2) & 3));
+  ctx->last_pb_fold = a->pb_fold;
+  ctx->last_pb_outputs = a->pb_outputs;
+  if (a->pb_fold) {
+    const int lab1 = (int)((ctx->opt_ablate >> 2) & 7);
+    const dim3 grid1((unsigned)a->pb_nb, (unsigned)split);
+#define SAMD_PB1F(LAB)                                                                                                 \
+  hipLaunchKernelGGL((pb_pass1f_kernel<T, 8, LAB>), grid1, dim3(kPbThreads), 0, ctx->stream,                            \
+                     (const int64_t *)a->pb_piece_ptr, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,            \
+                     (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w)
+    if (lab1 == 1) SAMD_PB1F(1);
+    else if (lab1 == 2) SAMD_PB1F(2);
+    else if (lab1 == 4) SAMD_PB1F(4);
+    else SAMD_PB1F(0);
+#undef SAMD_PB1F
+  }
+  else
+    hipLaunchKernelGGL((pb_pass1_kernel<T, 8>), dim3((unsigned)a->pb_nb, (unsigned)split), dim3(kPbThreads), 0, ctx->stream,
+                       (const int64_t *)a->pb_piece_ptr, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,
+                       (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w,
+                       (int)((ctx->opt_ablate >> 2) & 3));
   SAMD_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL((pb_pass2_kernel<T, 8>), dim3((unsigned)a->pb_np), dim3(kPbThreads), 0, ctx->stream,
                      (const int64_t *)(a->pb_piece_ptr + a->pb_nb + 1), (const int64_t *)a->pb_panel_row,
                      (const uint16_t *)a->pb_row16, (const T *)a->pb_prod, y, (int)(ctx->opt_ablate & 3),
-                     (ctx->opt_ablate & 3) == 2 ? 0 : (ctx->opt_ablate >> 4) ? (int)(ctx->opt_ablate >> 4) : kPbFoldMax);
+                     ((ctx->opt_ablate & 3) == 2 || a->pb_fold) ? 0 : (ctx->opt_ablate >> 5) ? (int)(ctx->opt_ablate >> 5) : kPbFoldMax);
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
 }

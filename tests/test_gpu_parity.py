@@ -358,16 +358,20 @@ def test_smvm_column_blocks(ctx, dtype, width):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+@pytest.mark.parametrize("fold", [-1, 1], ids=["plain", "folded"])
 @pytest.mark.parametrize("geom", [(0, 0, 0), (64, 2, 2048), (700, 5, 4096)], ids=["one_piece", "tiny", "mid"])
-def test_smvm_two_pass_panels(ctx, dtype, geom):
+def test_smvm_two_pass_panels(ctx, dtype, geom, fold):
     """spmv_pb=2 forces the two-pass product (normally kept for large, wide, skewed records of 4-byte values): entries regrouped
     into (row panel) x (column block) pieces, products streamed out, then added per panel.  The overrides
     shrink panels and blocks so that small records have many of both.  Against the oracle within the dtype's
     bar (the summation order differs from the oracle's), i32 exact; a second x on the cached pieces; a very
-    long row (longer than a panel's entry budget), empty rows, runs of them; the record itself untouched."""
+    long row (longer than a panel's entry budget), empty rows, runs of them; the record itself untouched.
+    fold = 1: the layout in which pass 1 adds up the products of one row inside one piece before writing them
+    (runs of 1 .. thousands of entries, cut at every 32nd position), -1: every product written."""
     O, M = Oracle(dtype), mk(ctx, dtype)
     rows, lines, entries = geom
     ctx.set_option("spmv_pb", 2)
+    ctx.set_option("spmv_pb_fold", fold)
     ctx.set_option("spmv_pb_rows", rows)
     ctx.set_option("spmv_pb_lines", lines)
     ctx.set_option("spmv_pb_entries", entries)
@@ -382,11 +386,12 @@ def test_smvm_two_pass_panels(ctx, dtype, geom):
             A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
             x = synth.uniform_values(5, m, dtype)
             close(M.sr.smvm(A, x), O.sr_smvm(Ao, x), dtype)
+            assert ctx.get_option("spmv_last_path") == 3 and ctx.get_option("spmv_last_pb_fold") == (fold > 0)
             x2 = synth.uniform_values(6, m, dtype)
             close(M.sr.smvm(A, x2), O.sr_smvm(Ao, x2), dtype)
             assert_same_record(A, Ao)
     finally:
-        for k in ("spmv_pb", "spmv_pb_rows", "spmv_pb_lines", "spmv_pb_entries"):
+        for k in ("spmv_pb", "spmv_pb_rows", "spmv_pb_lines", "spmv_pb_entries", "spmv_pb_fold"):
             ctx.set_option(k, 0)
 
 
