@@ -290,6 +290,7 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
   __shared__ uint32_t s_chunk;
   __shared__ unsigned long long s_off;
   __shared__ int s_fail;
+  __shared__ unsigned long long s_fmin, s_fmax;
   uint64_t *scomp = reinterpret_cast<uint64_t *>(raw);
   P *spay = reinterpret_cast<P *>(raw + kR1);
   uint32_t *C = reinterpret_cast<uint32_t *>(raw);
@@ -302,6 +303,8 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
   if (tid == 0) {
     s_chunk = atomicAdd(ticket, 1u);
     s_fail = 0;
+    s_fmin = ~0ull;
+    s_fmax = 0ull;
   }
   __syncthreads();
   const uint32_t chunk = s_chunk;
@@ -334,11 +337,17 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
   uint64_t comp[ITEMS];
   uint32_t rank[ITEMS];
   const uint32_t pbase = (uint32_t)tid * (uint32_t)R;
-  const int lowbits = tb;  // begin_bit = 0
-  const uint64_t lowmask = (1ull << lowbits) - 1ull;
+  // The low tb bits of a key are (row bits below the buckets | column), or just the column's low bits when the
+  // buckets already split rows.  Inside a chunk the column part F spans far less than its field on banded and stencil
+  // records (C2: ~9000 of 2^24), so the chunk sorts F - min(F) in as many bits as its span needs: C2 34 -> 24 sorted
+  // bits, five in-LDS passes instead of seven.
+  const int fbits = tb < minor_bits ? tb : minor_bits;
+  const uint64_t fmask = (1ull << fbits) - 1ull;  // fbits <= tb < 64
+  const uint64_t lowmask_in = (1ull << tb) - 1ull;
   uint32_t heads = 0;
   {
     uint64_t before = (pbase > 0 && pbase < L) ? scomp[rl_pad(pbase - 1)] : 0ull;
+    uint64_t fmn = ~0ull, fmx = 0ull;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
       const uint32_t p = pbase + k;
@@ -348,10 +357,25 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
       heads += head ? 1u : 0u;
       rank[k] = head ? (heads | 0x80000000u) : heads;  // inclusive count in the thread, top bit = bucket head
       before = comp[k];
+      if (live) {
+        const uint64_t f = comp[k] & fmask;
+        fmn = f < fmn ? f : fmn;
+        fmx = f > fmx ? f : fmx;
+      }
+    }
+    fmn = wave_reduce(fmn, OpMin());
+    fmx = wave_reduce(fmx, OpMax());
+    if ((tid & 63) == 0) {
+      atomicMin(&s_fmin, (unsigned long long)fmn);
+      atomicMax(&s_fmax, (unsigned long long)fmx);
     }
   }
   uint32_t nbk;
   const uint32_t hex = block_exclusive_add<uint32_t>(heads, shs, nbk);  // ends with a barrier: every key is in registers
+  const uint64_t fmin = s_fmin, fspan = s_fmax - fmin;  // L > 0: some thread held a live pair
+  const int fb2 = fspan == 0 ? 0 : 64 - __builtin_clzll(fspan);  // bits of F - fmin
+  const int lowbits = (tb - fbits) + fb2;                         // what the chunk sorts below the bucket ordinal
+  const uint64_t lowmask = (1ull << lowbits) - 1ull, fmask2 = (1ull << fb2) - 1ull;
   if (nbk > (uint32_t)kRlMaxBuckets) {
     if (tid < 64) {
       bool fail;
@@ -370,7 +394,8 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
     if (k < R && p < L) {
       const uint32_t o = hex + (rank[k] & 0x7fffffffu) - 1u;
       if (rank[k] & 0x80000000u) top_tab[o] = (uint32_t)(comp[k] >> tb);
-      comp[k] = ((((uint64_t)o << lowbits) | (comp[k] & lowmask)) << kRlTagBits) | p;
+      const uint64_t low = (((comp[k] & lowmask_in) >> fbits) << fb2) | ((comp[k] & fmask) - fmin);
+      comp[k] = ((((uint64_t)o << lowbits) | low) << kRlTagBits) | p;
     }
   }
   const int ordbits = nbk > 1 ? 32 - __builtin_clz(nbk - 1) : 0;
@@ -455,6 +480,10 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
       if (!fail && last_chunk) *merged_out = off + U;
     }
   }
+  auto rl_key = [&](uint64_t id) -> uint64_t {  // the key a sorted composite (tag shifted out) stands for
+    const uint64_t low = id & lowmask;
+    return ((uint64_t)top_tab[(uint32_t)(id >> lowbits)] << tb) | ((low >> fb2) << fbits) | ((low & fmask2) + fmin);
+  };
   I ocol[ITEMS];
   T oval[ITEMS];
   uint32_t endmask = 0;
@@ -467,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
     orow[k] = 0;
     if (k < R && p < L) {
       const uint64_t id = comp[k] >> kRlTagBits;
-      const uint64_t key = ((uint64_t)top_tab[(uint32_t)(id >> lowbits)] << tb) | (id & lowmask);
+      const uint64_t key = rl_key(id);
       if ((headmask & (1u << k)) && !(lab & 0x800)) {
         auto value_at = [&](uint64_t c) -> T {
           const P pv = spay[rl_pad((uint32_t)c & ((1u << kRlTagBits) - 1u))];
@@ -487,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
       bool rend = p + 1 >= L;
       if (!rend) {
         const uint64_t nid = scomp[rl_pad(p + 1)] >> kRlTagBits;
-        const uint64_t nkey = ((uint64_t)top_tab[(uint32_t)(nid >> lowbits)] << tb) | (nid & lowmask);
+        const uint64_t nkey = rl_key(nid);
         rend = (minor_bits >= 64 ? 0ull : (nkey >> minor_bits)) != (minor_bits >= 64 ? 0ull : (key >> minor_bits));
       }
       if (rend && !(lab & 0x200)) {

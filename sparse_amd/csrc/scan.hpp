@@ -22,6 +22,10 @@ struct OpAdd {
   template <class V>
   __device__ __forceinline__ V operator()(V a, V b) const { return a + b; }
 };
+struct OpMin {
+  template <class V>
+  __device__ __forceinline__ V operator()(V a, V b) const { return a < b ? a : b; }
+};
 struct OpMax {
   template <class V>
   __device__ __forceinline__ V operator()(V a, V b) const { return a > b ? a : b; }
