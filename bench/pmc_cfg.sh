@@ -11,7 +11,7 @@ import csv, sys, collections, os
 acc = collections.defaultdict(lambda: [0.0, 0])
 for row in csv.DictReader(open(sys.argv[1])):
     k = row["Kernel_Name"]
-    if os.environ.get("KFILTER", "spmm") not in k: continue
+    if not any(f in k for f in os.environ.get("KFILTER", "spmm").split(",")): continue
     key = (k.split("(")[0][-60:], row["Counter_Name"])
     acc[key][0] += float(row["Counter_Value"]); acc[key][1] += 1
 for (k, c), (v, n) in sorted(acc.items()):

@@ -11,6 +11,6 @@ cd $GRAFT_REPO_ROOT && timeout -k 10 600 python bench/configs.py c1 c2 c3 c4 c5r
 grep "^{" $OUT/${TAG}_configs.log > $OUT/${TAG}_configs.jsonl; cat $OUT/${TAG}_configs.jsonl
 cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_cfg -o configs -- python3 $GRAFT_REPO_ROOT/bench/configs.py c1 c2 c3 c4 c5r --steps 10 > $OUT/${TAG}_prof_cfg.log 2>&1 || { tail -5 $OUT/${TAG}_prof_cfg.log; exit 1; }
 cd $GRAFT_REPO_ROOT && bash bench/pmc_traffic.sh > $OUT/${TAG}_pmc_traffic.log 2>&1 || { tail -5 $OUT/${TAG}_pmc_traffic.log; exit 1; }
-CFG=c3 KFILTER=pb_pass PASSES="0 1 2 3" bash bench/pmc_cfg.sh > $OUT/${TAG}_pmc_two_pass_c3.txt 2>&1 || { tail -5 $OUT/${TAG}_pmc_two_pass_c3.txt; exit 1; }
-CFG=c5r KFILTER=pb_pass PASSES="0 1 2" bash bench/pmc_cfg.sh > $OUT/${TAG}_pmc_two_pass_c5r.txt 2>&1 || { tail -5 $OUT/${TAG}_pmc_two_pass_c5r.txt; exit 1; }
+CFG=c3 KFILTER=pb_pass,pb_xperm PASSES="0 1 2 3" bash bench/pmc_cfg.sh > $OUT/${TAG}_pmc_two_pass_c3.txt 2>&1 || { tail -5 $OUT/${TAG}_pmc_two_pass_c3.txt; exit 1; }
+CFG=c5r KFILTER=pb_pass,pb_xperm PASSES="0 1 2" bash bench/pmc_cfg.sh > $OUT/${TAG}_pmc_two_pass_c5r.txt 2>&1 || { tail -5 $OUT/${TAG}_pmc_two_pass_c5r.txt; exit 1; }
 echo PROFILE_DONE

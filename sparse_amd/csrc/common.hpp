@@ -122,6 +122,7 @@ struct futhark_context {
   int64_t opt_spmv_pb_rows = 0, opt_spmv_pb_lines = 0, opt_spmv_pb_entries = 0;  // test overrides: rows per panel,
                                                                                  // 32-column lines per block, entries per panel
   int64_t opt_spmv_pb_fold = 0;  // two-pass SpMV, products of one row inside one piece summed in pass 1: 0 when it shortens the product stream by >= 15 %, 1 always, -1 never
+  int64_t opt_spmv_pb_deal = 0;    // lines into column blocks: 0 sorted by popularity for skewed records (with the folded layout), dealt round otherwise; 1 always sorted; -1 always dealt
   int64_t opt_spmv_pb_oround = 0;  // lab: folded layout, alignment of a piece's outputs in products (0 = kPbOutRound)
   int64_t last_pb_fold = 0;      // 1 if the last two-pass product ran on a folded layout; last_pb_outputs: products it wrote (pads included)
   int64_t last_pb_outputs = 0;
@@ -281,6 +282,8 @@ struct CsrBody {
   mutable int pb_state = 0;  // 0 undecided, 1 active, -1 rejected
   mutable int pb_fold = 0;   // 1: folded layout (pb_col16 bit 15 = first entry of a run, pb_dgroup = first output of every group of 32 entries)
   mutable int64_t pb_outputs = 0;  // products pass 1 writes (pads included)
+  mutable int64_t *pb_wtab = nullptr;  // folded layout: [pb_nwg][3] pass 1's shares (first entry, end, column block)
+  mutable int64_t pb_nwg = 0;
   mutable int64_t pb_np = 0, pb_nb = 0, pb_w = 0, pb_nl = 0;  // panels, column blocks, columns per block, 32-column lines
   mutable int64_t *pb_panel_row = nullptr;   // [np + 1] first row of every panel
   mutable int64_t *pb_piece_ptr = nullptr;   // [np * nb + 1] start of every piece, panel-major
@@ -330,6 +333,7 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->pb_prod);
   dfree(ctx, b->pb_x);
   dfree(ctx, b->pb_dgroup);
+  dfree(ctx, b->pb_wtab);
   if (b->tb_ext_free) b->tb_ext_free(ctx, b->tb_ext);
   delete b;
 }

@@ -358,8 +358,8 @@ int tb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted) {
                                                     nl, 0, 32, &ks, &perm, sort_err)));
     SAMD_HIP(ctx, hipMemcpyAsync(line_of_rank.p, perm, sizeof(uint32_t) * (size_t)nl, hipMemcpyDeviceToDevice,
                                  ctx->stream));
-    hipLaunchKernelGGL(pb_rank_kernel, dim3(lgrid), dim3(kBlock), 0, ctx->stream, (const uint32_t *)line_of_rank.p, nl,
-                       rank_of_line.p);
+    hipLaunchKernelGGL(pb_rank_kernel, dim3(lgrid), dim3(kBlock), 0, ctx->stream, (const uint32_t *)perm, nl, (int64_t)1,
+                       nl, 0, rank_of_line.p, line_of_rank.p);  // dealt: place = rank
     SAMD_LAUNCH_CHECK(ctx);
     // ---- estimated entries per piece, then the entries sorted by (panel, thin, block); stable: a piece keeps
     // the record's (row, column) order, so the entries of one row are consecutive inside a piece

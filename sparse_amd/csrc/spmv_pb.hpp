@@ -70,10 +70,19 @@ __global__ __launch_bounds__(kBlock) void pb_line_count_kernel(const int32_t *__
     atomicAdd(&counts[col[i * stride] / kPbLine], 1u);
 }
 
-__global__ __launch_bounds__(kBlock) void pb_rank_kernel(const uint32_t *__restrict__ line_of_rank, int64_t nl,
-                                                         uint32_t *__restrict__ rank_of_line) {
+// Place q' of the line of popularity rank q: block q' mod nb, slot q' / nb.  Dealt (q' = q): the lines go round the
+// blocks, every block holds about the same number of entries.  Sorted (q' = (q mod lpb) * nb + q / lpb): block 0 holds
+// the lpb most popular lines, block 1 the next, ... -- a row then meets its entries in few blocks and pass 1 can add
+// most of them up (folded layout below).  place_line[q'] = the line at place q' (0xffffffff: none).
+__global__ __launch_bounds__(kBlock) void pb_rank_kernel(const uint32_t *__restrict__ line_of_rank, int64_t nl, int64_t nb,
+                                                         int64_t lpb, int sorted, uint32_t *__restrict__ rank_of_line,
+                                                         uint32_t *__restrict__ place_line) {
   const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (q < nl) rank_of_line[line_of_rank[q]] = (uint32_t)q;
+  if (q >= nl) return;
+  const int64_t q2 = sorted ? (q % lpb) * nb + q / lpb : q;
+  const uint32_t line = line_of_rank[q];
+  rank_of_line[line] = (uint32_t)q2;
+  place_line[q2] = line;
 }
 
 // key of entry e = (block * np + panel) * 32 + (row inside the panel) mod 32: block-major (pass 1 streams a block's
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void pb_dgroup_kernel(const int64_t *__rest
   for (int64_t g = g0; g < g1; g++) dgroup[g] = (uint32_t)(d0 + (g - g0));
 }
 
-// x in block order: line of rank q -> block q mod nb, slot q / nb; w = columns per block
+// x in block order: the line at place q -> block q mod nb, slot q / nb; w = columns per block; nl = places
 template <class T>
 __global__ __launch_bounds__(kBlock) void pb_xperm_kernel(const T *__restrict__ x, int64_t m,
                                                           const uint32_t *__restrict__ line_of_rank, int64_t nl,
@@ -190,8 +199,9 @@ __global__ __launch_bounds__(kBlock) void pb_xperm_kernel(const T *__restrict__ 
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t q = t / kPbLine, j = t % kPbLine;
   if (q >= nl) return;
-  const int64_t c = (int64_t)line_of_rank[q] * kPbLine + j;
-  xperm[(q % nb) * w + (q / nb) * kPbLine + j] = c < m ? x[c] : (T)0;
+  const uint32_t line = line_of_rank[q];  // the line at place q
+  const int64_t c = (int64_t)line * kPbLine + j;
+  xperm[(q % nb) * w + (q / nb) * kPbLine + j] = (line != 0xffffffffu && c < m) ? x[c] : (T)0;
 }
 
 __device__ __forceinline__ int64_t cdiv_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -471,15 +481,17 @@ __device__ __forceinline__ P *pb_uniform_ptr(P *p) {  // p is the same in every 
   return (P *)(G *)(((uint64_t)hi << 32) | lo);
 }
 
-// LAB (kernel lab, results wrong): 1 no store, 2 no LDS gather, 3 plain store, 4 no run sums
+// LAB (kernel lab; results wrong for 1, 2, 4): 1 no store, 2 no LDS gather, 3 non-temporal stores, 4 no run sums
 template <class T, int U, int LAB>
-__global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__restrict__ block_ptr,
+__global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__restrict__ wtab,
                                                                const uint16_t *__restrict__ col16,
                                                                const T *__restrict__ pval, const T *__restrict__ xperm,
                                                                const uint32_t *__restrict__ uout,
                                                                T *__restrict__ prod, int w) {
   __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
-  const int64_t b = blockIdx.x;
+  // the workgroup's share: entries [s, e) of column block b (wtab: the blocks hold very different numbers of entries
+  // when the lines are sorted into them, so the shares are laid out by the host, pb_work_table)
+  const int64_t s = wtab[3 * (int64_t)blockIdx.x], e = wtab[3 * (int64_t)blockIdx.x + 1], b = wtab[3 * (int64_t)blockIdx.x + 2];
   {
     constexpr int PER = 16 / (int)sizeof(T);
     const raw16 *src = reinterpret_cast<const raw16 *>(xperm + b * (int64_t)w);
@@ -489,10 +501,6 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
   constexpr int kChunk = 64 * U;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const PbLane L(lane);
-  const int64_t s0 = block_ptr[b], e0 = block_ptr[b + 1];
-  const int64_t per = cdiv_dev(cdiv_dev(e0 - s0, kStep), (int64_t)gridDim.y) * kStep;
-  const int64_t s = s0 + (int64_t)blockIdx.y * per;
-  const int64_t e = s + per < e0 ? s + per : e0;
   __syncthreads();
   // A wavefront takes 64 U consecutive entries per step: runs are neighbouring lanes.  s, e and every step are
   // multiples of 32, so lanes 0 and 32 always sit on a forced run start.  The next step's entries are requested
@@ -511,9 +519,14 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
       g[u] = gp[(unsigned)(u * 2 + (lane >> 5))];
     }
   };
-  // (tried: the sums collected in a per-wavefront LDS row while consecutive groups continue each other's outputs and
-  // written as whole aligned 256-byte rows -- the bookkeeping per half group, scalar as it is, took pass 1 from 0.687
-  // to 0.91 ms on C3, stores or no stores; the direct form below writes ~19 sums per group of 32 entries where they fall)
+  // The sums are stored where they fall, a group's few at a time: short, unaligned pieces of lines, which the memory
+  // system charges per piece rather than per byte (C3, lines sorted into the blocks: 84 M sums = 0.34 GB cost 0.16 ms
+  // where the 2 GB of entries stream in 0.40).  Plain stores, so that L2 can put the pieces of a line together
+  // (non-temporal: pass 1 0.615 instead of 0.558 ms; the next kernel then pays 0.02 ms for the write-backs).
+  // Tried twice and dropped: collecting the sums in a per-wavefront row of LDS and writing whole aligned 256-byte
+  // rows -- (a) across piece boundaries with scalar bookkeeping per half group: 0.687 -> 0.91 ms; (b) only for steps
+  // whose 16 groups continue each other (a flag bit per group from the build, one test per step): 0.558 -> 0.584 ms,
+  // the LDS round trip costs more than the fuller lines save.
   auto work = [&](const uint32_t (&c)[U], const T (&v)[U], const uint32_t (&g)[U], int n) {  // n: entries of the step
     T pr[U];
 #pragma unroll
@@ -526,8 +539,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
       const uint32_t tails = L.half(heads >> 1) | (L.hi ? 0x80000000u : 0u);  // bit 31 of the low half: lane 32 starts a run
       if (ok && (tails & L.bit) != 0) {
         T *d = prod + ((int64_t)g[u] + __popc(tails & L.under));
-        if (LAB == 3) *d = sum;
-        else if (LAB != 1 || sum == (T)12345) __builtin_nontemporal_store(sum, d);
+        if (LAB == 3) __builtin_nontemporal_store(sum, d);
+        else if (LAB != 1 || sum == (T)12345) *d = sum;
       }
     }
   };
@@ -744,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void pbf_bounds_kernel(const int64_t *__res
 template <class T>
 int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, const uint32_t *eperm,
               const int64_t *piece_ptr, const int64_t *panel_row, const uint32_t *rank_of_line, int64_t nb, int64_t np,
-              int64_t pieces, bool *done) {
+              int64_t pieces, bool sorted, bool *done) {
   *done = false;
   const int64_t nnz = a->nnz;
   const unsigned egrid = (unsigned)cdiv(nnz, kBlock), pgrid = (unsigned)cdiv(pieces + 1, kBlock);
@@ -762,7 +775,9 @@ int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, co
   SAMD_TRY(read_small(ctx, ctx->d_small, 5, small));
   const int64_t runs = (int64_t)(uint32_t)(small[4] & 0xffffffff);
   if (ctx->logging) fprintf(stderr, "[sparse_amd] two-pass SpMV: %lld runs for %lld entries\n", (long long)runs, (long long)nnz);
-  if (ctx->opt_spmv_pb_fold <= 0 && (double)runs > 0.85 * (double)nnz) return 0;  // not worth the fold arithmetic
+  // not worth the fold arithmetic?  (With sorted blocks there is no other layout: the plain pass 1 splits every block
+  // into the same number of shares.)
+  if (!sorted && ctx->opt_spmv_pb_fold <= 0 && (double)runs > 0.85 * (double)nnz) return 0;
   if (runs + 33 * pieces >= (int64_t)0xffffff00LL) return 0;                      // 32-bit places and outputs
   Tmp<uint32_t> run_start(ctx), piece_run(ctx), run_slot(ctx), len(ctx);
   Tmp<int64_t> sbase(ctx), spos(ctx);
@@ -846,8 +861,40 @@ int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, co
                      (const int64_t *)sbase.p, (const int64_t *)spos.p, (const int64_t *)poff.p, np, nb, bounds.p);
   SAMD_LAUNCH_CHECK(ctx);
   SAMD_TRY(prod.get(ototal));
-  SAMD_HIP(ctx, hipMemsetAsync(prod.p, 0, sizeof(T) * (size_t)ototal, ctx->stream));  // output pads are read by pass 2 (into the trash slot)
-  SAMD_TRY(read_small(ctx, ctx->d_small, 1, small));  // orders the temporaries' release after their use
+  SAMD_HIP(ctx, hipMemsetAsync(prod.p, 0, sizeof(T) * (size_t)ototal, ctx->stream));  // output pads are read by pass 2 (into the trash slots)
+  // ---- pass 1's shares: about four workgroups per CU, every block cut into shares of whole steps in proportion to
+  // its entries (at least one)
+  std::vector<int64_t> hb((size_t)nb + 1);
+  SAMD_HIP(ctx, hipMemcpyAsync(hb.data(), bounds.p, sizeof(int64_t) * (size_t)(nb + 1), hipMemcpyDeviceToHost, ctx->stream));
+  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also orders the temporaries' release after their use
+  std::vector<int64_t> wt;
+  {
+    constexpr int64_t kStep = (int64_t)kPbThreads * 8;  // pb_pass1f_kernel<T, 8>
+    const int64_t target = (int64_t)ctx->num_cu * 4;
+    const int64_t total = hb[(size_t)nb] - hb[0] > 0 ? hb[(size_t)nb] - hb[0] : 1;
+    for (int64_t b = 0; b < nb; b++) {
+      const int64_t s0 = hb[(size_t)b], e0 = hb[(size_t)b + 1];
+      if (e0 <= s0) continue;
+      const int64_t steps = cdiv(e0 - s0, kStep);
+      int64_t shares = ((e0 - s0) * target + total / 2) / total;
+      if (shares < 1) shares = 1;
+      if (shares > steps) shares = steps;
+      const int64_t per = cdiv(steps, shares) * kStep;
+      for (int64_t s = s0; s < e0; s += per) {
+        wt.push_back(s);
+        wt.push_back(s + per < e0 ? s + per : e0);
+        wt.push_back(b);
+      }
+    }
+  }
+  Tmp<int64_t> wtab(ctx);
+  SAMD_TRY(wtab.get((int64_t)wt.size()));
+  if (!wt.empty()) {
+    SAMD_HIP(ctx, hipMemcpyAsync(wtab.p, wt.data(), sizeof(int64_t) * wt.size(), hipMemcpyHostToDevice, ctx->stream));
+    SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // wt is host memory that goes away
+  }
+  a->pb_wtab = wtab.release();
+  a->pb_nwg = (int64_t)wt.size() / 3;
   a->pb_piece_ptr = bounds.release();
   a->pb_dgroup = uout.release();
   a->pb_col16 = col16.release();
@@ -886,6 +933,10 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
   const int64_t nl = cdiv(a->m, kPbLine);
   const int64_t nb = cdiv(nl, lpb);
   const int64_t w = cdiv(nl, nb) * kPbLine;  // columns per block actually used (<= lpb * 32)
+  const int64_t nq = (w / kPbLine) * nb;     // places for lines (>= nl)
+  // lines sorted into the blocks by popularity (and pass 1 adding up what a row holds in a block) when the popularity
+  // is skewed: that is where rows meet the same few blocks again and again
+  const bool sorted = ctx->opt_spmv_pb_fold >= 0 && (ctx->opt_spmv_pb_deal > 0 || (ctx->opt_spmv_pb_deal == 0 && vetted && !flat));
   if (!force) {
     // the gather has to be the problem: 4-byte values (16 B moved per entry against 8; for 8-byte values the
     // one-pass paths are on par), x beyond the L2s, most tiles spanning a wide column range
@@ -937,7 +988,8 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
   Tmp<T> pval(ctx), prod(ctx), xperm(ctx);
   SAMD_TRY(panel_row.get(np + 1));
   SAMD_TRY(piece_ptr.get(pieces + 1));
-  SAMD_TRY(line_of_rank.get(nl));
+  SAMD_TRY(line_of_rank.get(nq));  // the line at every place
+  SAMD_HIP(ctx, hipMemsetAsync(line_of_rank.p, 0xff, sizeof(uint32_t) * (size_t)nq, ctx->stream));
   SAMD_HIP(ctx, hipMemcpyAsync(panel_row.p, cuts.data(), sizeof(int64_t) * (size_t)(np + 1), hipMemcpyHostToDevice,
                                ctx->stream));
   SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // cuts is host memory that goes away
@@ -969,10 +1021,8 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
     const uint32_t *perm = nullptr;
     SAMD_TRY((radix_sort_pairs<uint32_t, uint32_t>(ctx, counts.p, keys_b.p, (const uint32_t *)nullptr, pay_a.p, pay_b.p,
                                                     nl, 0, 32, &ks, &perm, sort_err)));
-    SAMD_HIP(ctx, hipMemcpyAsync(line_of_rank.p, perm, sizeof(uint32_t) * (size_t)nl, hipMemcpyDeviceToDevice,
-                                 ctx->stream));
-    hipLaunchKernelGGL(pb_rank_kernel, dim3(lgrid), dim3(kBlock), 0, ctx->stream, (const uint32_t *)line_of_rank.p, nl,
-                       rank_of_line.p);
+    hipLaunchKernelGGL(pb_rank_kernel, dim3(lgrid), dim3(kBlock), 0, ctx->stream, perm, nl, nb, w / kPbLine, sorted ? 1 : 0,
+                       rank_of_line.p, line_of_rank.p);
     SAMD_LAUNCH_CHECK(ctx);
     // ---- entries sorted by piece (stable: a piece keeps the record's (row, column) order)
     Tmp<uint32_t> ek_a(ctx), ek_b(ctx), ep_a(ctx), ep_b(ctx);
@@ -1000,7 +1050,7 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
     }
     if (ctx->opt_spmv_pb_fold >= 0)
       SAMD_TRY(pbf_build<T>(ctx, a, eks, eperm, (const int64_t *)piece_ptr.p, (const int64_t *)panel_row.p,
-                            (const uint32_t *)rank_of_line.p, nb, np, pieces, &folded));
+                            (const uint32_t *)rank_of_line.p, nb, np, pieces, sorted, &folded));
     if (!folded) {
     // ---- both padded layouts: every piece rounded up to a multiple of 32 entries
     Tmp<int64_t> boff(ctx), poff(ctx);
@@ -1051,7 +1101,7 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
   a->pb_np = np;
   a->pb_nb = nb;
   a->pb_w = w;
-  a->pb_nl = nl;
+  a->pb_nl = nq;  // places of lines in block order
   a->pb_panel_row = panel_row.release();
   if (a->pb_fold == 0) {
     a->pb_piece_ptr = bounds.release();  // [nb + 1] block ranges (block-major layout), then [np + 1] panel ranges (panel-major)
@@ -1079,17 +1129,19 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
   int64_t split = cdiv((int64_t)ctx->num_cu * 4, a->pb_nb);
   if (split < 1) split = 1;
   if (split > 65535) split = 65535;
-  ctx->last_pb_fold = a->pb_fold;
+  ctx->last_pb_fold = a->pb_fold ? 1 : 0;
   ctx->last_pb_outputs = a->pb_outputs;
   if (a->pb_fold) {
     const int lab1 = (int)((ctx->opt_ablate >> 2) & 7);
-    const dim3 grid1((unsigned)a->pb_nb, (unsigned)split);
+    const dim3 grid1((unsigned)a->pb_nwg);
 #define SAMD_PB1F(LAB)                                                                                                 \
-  hipLaunchKernelGGL((pb_pass1f_kernel<T, 8, LAB>), grid1, dim3(kPbThreads), 0, ctx->stream,                            \
-                     (const int64_t *)a->pb_piece_ptr, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,            \
+  hipLaunchKernelGGL((pb_pass1f_kernel<T, 8, LAB>), grid1    , dim3(kPbThreads), 0, ctx->stream,                        \
+                     (const int64_t *)a->pb_wtab, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,                 \
                      (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w)
-    if (lab1 == 1) SAMD_PB1F(1);
+    if (a->pb_nwg <= 0) {}  // nothing stored
+    else if (lab1 == 1) SAMD_PB1F(1);
     else if (lab1 == 2) SAMD_PB1F(2);
+    else if (lab1 == 3) SAMD_PB1F(3);
     else if (lab1 == 4) SAMD_PB1F(4);
     else SAMD_PB1F(0);
 #undef SAMD_PB1F

@@ -358,7 +358,7 @@ def test_smvm_column_blocks(ctx, dtype, width):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
-@pytest.mark.parametrize("fold", [-1, 1], ids=["plain", "folded"])
+@pytest.mark.parametrize("fold", [(-1, 0), (1, -1), (1, 1)], ids=["plain", "folded", "folded_sorted"])
 @pytest.mark.parametrize("geom", [(0, 0, 0), (64, 2, 2048), (700, 5, 4096)], ids=["one_piece", "tiny", "mid"])
 def test_smvm_two_pass_panels(ctx, dtype, geom, fold):
     """spmv_pb=2 forces the two-pass product (normally kept for large, wide, skewed records of 4-byte values): entries regrouped
@@ -367,11 +367,14 @@ def test_smvm_two_pass_panels(ctx, dtype, geom, fold):
     bar (the summation order differs from the oracle's), i32 exact; a second x on the cached pieces; a very
     long row (longer than a panel's entry budget), empty rows, runs of them; the record itself untouched.
     fold = 1: the layout in which pass 1 adds up the products of one row inside one piece before writing them
-    (runs of 1 .. thousands of entries, cut at every 32nd position), -1: every product written."""
+    (runs of 1 .. thousands of entries, cut at every 32nd position), -1: every product written; deal = 1: the
+    column lines sorted into the blocks by popularity (blocks of very different sizes) instead of dealt round them."""
     O, M = Oracle(dtype), mk(ctx, dtype)
     rows, lines, entries = geom
+    fold, deal = fold
     ctx.set_option("spmv_pb", 2)
     ctx.set_option("spmv_pb_fold", fold)
+    ctx.set_option("spmv_pb_deal", deal)
     ctx.set_option("spmv_pb_rows", rows)
     ctx.set_option("spmv_pb_lines", lines)
     ctx.set_option("spmv_pb_entries", entries)
@@ -391,7 +394,7 @@ def test_smvm_two_pass_panels(ctx, dtype, geom, fold):
             close(M.sr.smvm(A, x2), O.sr_smvm(Ao, x2), dtype)
             assert_same_record(A, Ao)
     finally:
-        for k in ("spmv_pb", "spmv_pb_rows", "spmv_pb_lines", "spmv_pb_entries", "spmv_pb_fold"):
+        for k in ("spmv_pb", "spmv_pb_rows", "spmv_pb_lines", "spmv_pb_entries", "spmv_pb_fold", "spmv_pb_deal"):
             ctx.set_option(k, 0)
 
 
