@@ -424,11 +424,20 @@ int radix_sort_pairs_onesweep(futhark_context *ctx, K *keys_a, K *keys_b, const 
   SAMD_TRY(incl.get(ngroups * kRsRadix));
   SAMD_HIP(ctx, hipMemsetAsync(ghist.p, 0, sizeof(uint32_t) * (size_t)gcount, ctx->stream));
   {
-    const int64_t cap = (int64_t)ctx->num_cu * 8;
-    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
-    hipLaunchKernelGGL((rs_hist_all<K, ITEMS>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const K *)keys_a,
-                       (uint32_t)n, begin_bit, end_bit, ghist.p);
-    SAMD_LAUNCH_CHECK(ctx);
+    // the kernel that packed these keys may have counted their top digits already (assembly.hpp: pack_coo_hist_kernel)
+    const bool pre = ctx->pre_hist != nullptr && ctx->pre_hist_keys == (const void *)keys_a && ctx->pre_hist_n == n &&
+                     ctx->pre_hist_end == end_bit && passes <= 3 && (end_bit - begin_bit) == 8 * passes;
+    if (pre) {
+      for (int p = 0; p < passes; p++)  // pass p sorts the digit at begin_bit + 8 p = top-aligned digit passes - 1 - p
+        SAMD_HIP(ctx, hipMemcpyAsync(ghist.p + p * kRsRadix, ctx->pre_hist + (passes - 1 - p) * kRsRadix,
+                                     sizeof(uint32_t) * kRsRadix, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+      const int64_t cap = (int64_t)ctx->num_cu * 8;
+      const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+      hipLaunchKernelGGL((rs_hist_all<K, ITEMS>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const K *)keys_a,
+                         (uint32_t)n, begin_bit, end_bit, ghist.p);
+      SAMD_LAUNCH_CHECK(ctx);
+    }
     hipLaunchKernelGGL(rs_scan_hist, dim3(passes), dim3(kBlock), 0, ctx->stream, ghist.p);
     SAMD_LAUNCH_CHECK(ctx);
   }
