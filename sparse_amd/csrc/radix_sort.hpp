@@ -69,6 +69,9 @@ __global__ __launch_bounds__(kBlock) void rs_scatter(const K *__restrict__ kin, 
   __shared__ uint32_t lstart[kRsRadix];       // start of each digit's run inside the sorted tile
   __shared__ uint32_t goff[kRsRadix];         // global offset of the run minus lstart
   __shared__ uint32_t shs[kWaves];
+  // (tried: one buffer for the re-ordered keys and then the payloads -- 39 instead of 71 KB for 16-byte pairs, three
+  // blocks per CU by registers instead of two by LDS, two more barriers: the pass 0.81 -> 0.765 ms on C2, the
+  // assembly as a whole unchanged within run-to-run noise and C4's slower; not kept)
   __shared__ K skey[TILE];
   __shared__ P spay[TILE];
 
@@ -239,6 +242,9 @@ __global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin,
   __shared__ uint32_t shs[kWaves];
   __shared__ uint32_t s_tile;
   __shared__ int s_fail;
+  // (tried: one buffer for the re-ordered keys and then the payloads -- 39 instead of 71 KB for 16-byte pairs, three
+  // blocks per CU by registers instead of two by LDS, two more barriers: the pass 0.81 -> 0.765 ms on C2, the
+  // assembly as a whole unchanged within run-to-run noise and C4's slower; not kept)
   __shared__ K skey[TILE];
   __shared__ P spay[TILE];
 
