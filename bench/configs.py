@@ -160,6 +160,8 @@ def main():
             run("C2 laplacian 4096^2", "f64", g * g, g * g, lambda: synth.laplacian_2d_coo_device(g, dev))
         elif cfg == "c3":
             run("C3 RMAT scale 24 ef 18", "f32", 1 << 24, 1 << 24, lambda: synth.rmat_coo_device(24, 18, dev, "f32"))
+        elif cfg == "c3d":   # the same graph with 8-byte values
+            run("lab: RMAT scale 24 ef 18, f64", "f64", 1 << 24, 1 << 24, lambda: synth.rmat_coo_device(24, 18, dev, "f64"))
         elif cfg == "c3s":
             run("C3-small RMAT scale 20 ef 18", "f32", 1 << 20, 1 << 20, lambda: synth.rmat_coo_device(20, 18, dev, "f32"))
         elif cfg == "c4":

@@ -944,7 +944,9 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
     // renumbering is on par).  Flat popularity (uniform random: no renumbering can help, every gather of the
     // one-pass kernels misses L2): any value size -- measured f64, m = 1e7: 100 entries per row 0.78 ms against
     // 1.04 with column blocks, 12.5 per row 0.89 against 2.42, the 1e9-entry record 5.7 against 6.3.
-    if ((sizeof(T) != 4 && !flat) || a->m * (int64_t)sizeof(T) < kPbMinBytes) return 0;
+    // (8-byte values with skewed popularity: only with the lines sorted into the blocks and the folded layout, which
+    // writes a fraction of the products)
+    if ((sizeof(T) != 4 && !flat && !sorted) || a->m * (int64_t)sizeof(T) < kPbMinBytes) return 0;
     const int64_t np_est = cdiv(a->n, R) + cdiv(a->nnz, E);
     if (a->nnz / (np_est * nb) < kPbMinPiece) return 0;
   }

@@ -225,6 +225,43 @@ def test_c3_two_pass_product_is_chosen_and_within_tolerance():
     assert torch.equal(yi, yi2)
 
 
+def test_skewed_f64_record_takes_the_folded_two_pass_product():
+    """RMAT scale 22 with 8-byte values: the lines of columns are sorted into the blocks by popularity and pass 1 adds
+    up what a row holds in a piece, which is what makes two passes pay for 8-byte values (scale 24: 2.45 -> 1.46 ms).
+    Against the plain one-pass kernel on a fresh record within the f64 bar, against torch's scatter-add, and the
+    dealt, unfolded layout forced on the same record for comparison."""
+    torch, ctx = _ctx()
+    from sparse_amd import mk_compressed, synth
+    n = 1 << 22
+    r, c, v = synth.rmat_coo_device(22, 18, "cuda:0", "f64")
+    x = torch.rand(n, device="cuda:0", dtype=torch.float64) + 0.5
+    M = mk_compressed("f64", ctx)
+    A = M.sr.sparse(n, n, (r, c, v))
+    y = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0").clone()
+    assert ctx.get_option("spmv_last_path") == 3 and ctx.get_option("spmv_last_pb_fold") == 1
+    assert ctx.get_option("spmv_last_pb_outputs") < 0.7 * A.stored_dims()[2]     # most products are summed in pass 1
+    want = torch.zeros(n, device="cuda:0", dtype=torch.float64).index_add_(0, r, v * x[c])
+    nz = want > 0
+    assert float(((y - want).abs()[nz] / want[nz]).max()) <= 1e-12
+    del A
+    ctx.clear_caches()
+    for opts, path in (({"spmv_pb": -1, "spmv_reorder": -1}, 0), ({"spmv_pb": 2, "spmv_pb_fold": -1}, 3)):
+        for k, val in opts.items():
+            ctx.set_option(k, val)
+        try:
+            A2 = M.sr.sparse(n, n, (r, c, v))
+            y2 = torch.as_tensor(M.sr.smvm(A2, x), device="cuda:0").clone()
+            assert ctx.get_option("spmv_last_path") == path
+            if path == 3:
+                assert ctx.get_option("spmv_last_pb_fold") == 0
+            assert float(((y - y2).abs() / y2.abs().clamp_min(1e-300)).max()) <= 1e-12
+            del A2
+        finally:
+            for k in opts:
+                ctx.set_option(k, 0)
+        ctx.clear_caches()
+
+
 @pytest.mark.parametrize("dtype,sorted_input", [("f32", False), ("i32", False), ("f64", False), ("f64", True)])
 def test_assembly_second_sort_equals_the_lsd_sort_at_scale(dtype, sorted_input):
     """3e7 uniform random triples on 4e6 x 4e6 (44 key bits, ~0.01 % duplicate coordinates): in auto mode the
