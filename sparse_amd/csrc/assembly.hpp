@@ -294,6 +294,110 @@ __global__ __launch_bounds__(kBlock) void merge_emit_kernel(const K *__restrict_
   if (!has_next || shr_safe<K>(knext, minor_bits) != major) row_ptr[(int64_t)major + 1] = (int64_t)s;
 }
 
+// Head flags, their scan, the fold and the emission in ONE read of the sorted pairs: a workgroup takes a tile of
+// kFoldTile consecutive sorted pairs (tiles by ticket), counts its run heads, learns how many outputs all earlier
+// tiles hold from a decoupled look-back over one status word per tile (rl_lookback, as the in-LDS sort's emission
+// does) and writes col_idx / vals / row ends.  Replaces scan_reduce + scan_apply + merge_emit_kernel, which between
+// them read the keys four times and wrote and read a 4-byte slot per pair (C3: 3.3 of the assembly's 18.9 ms), and
+// the host synchronisation that sized the output arrays between them (they are sized for the input here and cut
+// down afterwards if few pairs survive).  A run is folded by the thread that holds its first pair, left to right
+// (the reference's order), wherever the run ends.
+constexpr int kFoldItems = 16;
+constexpr int kFoldTile = kBlock * kFoldItems;
+
+template <class K, class T, class I, bool INDIRECT>
+__global__ __launch_bounds__(kBlock) void fold_emit_kernel(const K *__restrict__ keys, const uint32_t *__restrict__ perm,
+                                                           const T *__restrict__ vals_in, uint32_t count, int minor_bits,
+                                                           K minor_mask, I *__restrict__ col_out, T *__restrict__ vals_out,
+                                                           int64_t *__restrict__ row_ptr,
+                                                           unsigned long long *__restrict__ status,
+                                                           uint32_t *__restrict__ ticket,
+                                                           unsigned long long *__restrict__ merged_out,
+                                                           int *__restrict__ err, int lab) {
+  __shared__ uint32_t sh[kWaves];
+  __shared__ uint32_t s_tile;
+  __shared__ unsigned long long s_off;
+  __shared__ int s_fail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    s_tile = atomicAdd(ticket, 1u);
+    s_fail = 0;
+  }
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t ntiles = (count + kFoldTile - 1) / kFoldTile;
+  const uint32_t base = tile * (uint32_t)kFoldTile + (uint32_t)wave * (kFoldItems * 64) + (uint32_t)lane;  // layout rule of scan.hpp
+  K k[kFoldItems], kn[kFoldItems];
+  T val[kFoldItems];
+  uint32_t v[kFoldItems];
+  uint32_t headmask = 0;
+#pragma unroll
+  for (int j = 0; j < kFoldItems; j++) {
+    const uint32_t i = base + j * 64;
+    const bool ok = i < count;
+    const uint32_t ic = ok ? i : count - 1;  // clamped, never predicated
+    k[j] = keys[ic];
+    const K kp = keys[ic > 0 ? ic - 1 : 0];
+    kn[j] = keys[ic + 1 < count ? ic + 1 : ic];
+    // every pair's value is requested here, with the keys and ahead of the scan and the look-back: fetched where it
+    // is used (behind the `head` branch, one row of the tile after the other) each load was waited for on its own
+    val[j] = vals_in[(INDIRECT && perm) ? (int64_t)perm[ic] : (int64_t)ic];
+    const bool head = ok && (i == 0 || kp != k[j]);
+    headmask |= head ? (1u << j) : 0u;
+    v[j] = head ? 1u : 0u;
+  }
+  uint32_t total;
+  block_scan_striped<uint32_t, OpAdd, kFoldItems>(v, 0u, OpAdd(), sh, total);  // v[j]: heads up to and including pair j
+  if (tid < 64) {  // wave 0: the tile's first output slot; the other waves fold their runs meanwhile
+    bool fail = false;
+    const unsigned long long off = (lab & 1) ? (unsigned long long)tile * kFoldTile : rl_lookback(status, tile, total, &fail);
+    if (tid == 0) {
+      if (fail) {
+        *err = 1;
+        s_fail = 1;
+      }
+      s_off = off;
+      if (!fail && tile + 1 == ntiles) *merged_out = off + total;
+    }
+  }
+  // ---- fold: a run's first pair adds the rest of the run, left to right.  The second pair of a run is the next
+  // lane's (same j): its value and the key behind it come by a lane shift, so the common run of two costs no load;
+  // longer runs, and runs that start in lane 63, go on from global memory.  (With a global load per step, nearly
+  // every one of the tile's rows of 64 pairs had some lane waiting for two dependent loads on a power-law input:
+  // 1 ms of the kernel's 2.8 on C3.)
+#pragma unroll
+  for (int j = 0; j < kFoldItems; j++) {
+    const T vnext = wshfl_down(val[j], 1);
+    const K knext2 = wshfl_down(kn[j], 1);  // the key two places on
+    if (!(headmask & (1u << j)) || (lab & 2)) continue;
+    const uint32_t i = base + j * 64;
+    if (i + 1 >= count || kn[j] != k[j]) continue;
+    auto src = [&](uint32_t q) -> int64_t { return (INDIRECT && perm) ? (int64_t)perm[q] : (int64_t)q; };
+    uint32_t q = i + 1;
+    if (lane < 63) {
+      val[j] = (T)(val[j] + vnext);
+      q = i + 2;
+      if (q >= count || knext2 != k[j]) continue;
+    }
+    for (; q < count && keys[q] == k[j]; q++) val[j] = (T)(val[j] + vals_in[src(q)]);
+  }
+  __syncthreads();
+  if (s_fail) return;
+  const unsigned long long off = s_off;
+#pragma unroll
+  for (int j = 0; j < kFoldItems; j++) {
+    const uint32_t i = base + j * 64;
+    if (i >= count) continue;
+    const unsigned long long s = off + v[j];  // inclusive: outputs up to and including this pair's run
+    if (headmask & (1u << j)) {
+      col_out[s - 1] = (I)(k[j] & minor_mask);
+      if (!(lab & 4)) vals_out[s - 1] = val[j];
+    }
+    const K major = shr_safe<K>(k[j], minor_bits);
+    if (i + 1 >= count || shr_safe<K>(kn[j], minor_bits) != major) row_ptr[(int64_t)major + 1] = (int64_t)s;
+  }
+}
+
 // The same for keys known to be distinct (a record being transposed): slot = position, nothing to fold, no head
 // flags to scan.
 template <class K, class T, class I>
@@ -558,6 +662,73 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
       int64_t flags[1];
       SAMD_TRY(read_small(ctx, ctx->d_small + 2, 1, flags));  // the sort's look-back flag; also keeps the temporaries alive until the work is done
       if ((int)(flags[0] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
+      SAMD_TRY(build_plan(ctx, b));
+      *out = guard.release();
+      return 0;
+    }
+    const K minor_mask_f = minor_bits >= (int)(sizeof(K) * 8) ? (K)~(K)0 : (K)(((K)1 << minor_bits) - 1);
+    if (!ctx->sort_force_scan && ctx->opt_sort_algo == 0 && ctx->opt_fold_emit >= 0 && count < 0xffffffffLL) {
+      // one kernel: head flags, their scan (look-back over tiles), fold, emission (fold_emit_kernel)
+      const bool c32 = use_col32(ctx, n_minor);
+      SAMD_TRY(dalloc(ctx, &b->vals, count));
+      if (c32) SAMD_TRY(dalloc(ctx, &b->col32, count));
+      else SAMD_TRY(dalloc(ctx, &b->col64, count));
+      const int64_t ftiles = cdiv(count, kFoldTile);
+      Tmp<unsigned long long> fstatus(ctx);
+      Tmp<uint32_t> fticket(ctx);
+      SAMD_TRY(fstatus.get(ftiles));
+      SAMD_TRY(fticket.get(1));
+      SAMD_HIP(ctx, hipMemsetAsync(fstatus.p, 0, sizeof(unsigned long long) * (size_t)ftiles, ctx->stream));
+      SAMD_HIP(ctx, hipMemsetAsync(fticket.p, 0, sizeof(uint32_t), ctx->stream));
+      SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t) * 2, ctx->stream));
+      unsigned long long *merged_dev = reinterpret_cast<unsigned long long *>(ctx->d_small);
+      if (c32)
+        hipLaunchKernelGGL((fold_emit_kernel<K, T, int32_t, true>), dim3((unsigned)ftiles), dim3(kBlock), 0, ctx->stream,
+                           (const K *)ks, perm, vs, (uint32_t)count, minor_bits, minor_mask_f, b->col32, b->vals, b->row_ptr,
+                           fstatus.p, fticket.p, merged_dev, sort_err, (int)((ctx->opt_ablate >> 20) & 7));
+      else
+        hipLaunchKernelGGL((fold_emit_kernel<K, T, int64_t, true>), dim3((unsigned)ftiles), dim3(kBlock), 0, ctx->stream,
+                           (const K *)ks, perm, vs, (uint32_t)count, minor_bits, minor_mask_f, b->col64, b->vals, b->row_ptr,
+                           fstatus.p, fticket.p, merged_dev, sort_err, (int)((ctx->opt_ablate >> 20) & 7));
+      SAMD_LAUNCH_CHECK(ctx);
+      if (err_flag)
+        SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 1, err_flag, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+      int64_t host[4];
+      SAMD_TRY(read_small(ctx, ctx->d_small, 4, host));
+      if (ctx->opt_sort_inject && allow_retry) host[2] = 1;
+      if ((int)(host[2] & 0xffffffff) != 0) {  // a look-back wait ran into its limit (GPU shared or preempted)
+        if (!allow_retry) return set_error(ctx, "internal: radix sort look-back timed out");
+        ctx->last_sort_msd = -2;
+        return kAssembleAgain;
+      }
+      if ((int)(host[1] & 0xffffffff) != 0)
+        return set_error(ctx, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
+      merged = host[0];
+      b->nnz = merged;
+      if (merged * 4 < count * 3) {  // many duplicates: do not keep count-sized arrays for the record's lifetime
+        T *v2 = nullptr;
+        SAMD_TRY(dalloc(ctx, &v2, merged));
+        SAMD_HIP(ctx, hipMemcpyAsync(v2, b->vals, sizeof(T) * (size_t)merged, hipMemcpyDeviceToDevice, ctx->stream));
+        dfree(ctx, b->vals);
+        b->vals = v2;
+        if (c32) {
+          int32_t *c2 = nullptr;
+          SAMD_TRY(dalloc(ctx, &c2, merged));
+          SAMD_HIP(ctx, hipMemcpyAsync(c2, b->col32, sizeof(int32_t) * (size_t)merged, hipMemcpyDeviceToDevice, ctx->stream));
+          dfree(ctx, b->col32);
+          b->col32 = c2;
+        } else {
+          int64_t *c2 = nullptr;
+          SAMD_TRY(dalloc(ctx, &c2, merged));
+          SAMD_HIP(ctx, hipMemcpyAsync(c2, b->col64, sizeof(int64_t) * (size_t)merged, hipMemcpyDeviceToDevice, ctx->stream));
+          dfree(ctx, b->col64);
+          b->col64 = c2;
+        }
+      }
+      if (n_major > 0)
+        SAMD_TRY((device_scan<int64_t, OpMax, PtrIn<int64_t>, false>(ctx, PtrIn<int64_t>{b->row_ptr + 1}, n_major,
+                                                                      (int64_t)0, OpMax(), b->row_ptr + 1,
+                                                                      (int64_t *)nullptr)));
       SAMD_TRY(build_plan(ctx, b));
       *out = guard.release();
       return 0;

@@ -130,6 +130,7 @@ struct futhark_context {
   int64_t opt_spmv_2d_rows = 0, opt_spmv_2d_cols = 0, opt_spmv_2d_entries = 0, opt_spmv_2d_dense = 0;  // test / lab overrides
   int64_t opt_sort_indirect = 0;  // lab: 1 = assembly sorts 8-byte values by 4-byte source index and gathers them at the end
   int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
+  int64_t opt_fold_emit = 0;       // assembly after an LSD sort: 0 = head flags, scan, fold and emission in one kernel (look-back), -1 = scan + merge_emit
   int64_t opt_add_sort = 0;        // lab/tests: 1 = sr.+ / sr.- sort the concatenated entries instead of merging the two runs
   int64_t opt_sort_inject = 0;     // tests: 1 = the next assembly's first attempt is treated as if a look-back wait had timed out
   bool sort_force_scan = false;    // set while an assembly is repeated after a look-back wait timed out: histogram + scan passes only

@@ -43,6 +43,8 @@ template <class V>
 __device__ __forceinline__ V wshfl(V v, int src) { return __shfl(v, src, 64); }
 template <class V>
 __device__ __forceinline__ V wshfl_xor(V v, int m) { return __shfl_xor(v, m, 64); }
+template <class V>
+__device__ __forceinline__ V wshfl_down(V v, int d) { return __shfl_down(v, d, 64); }
 
 // Inclusive add-scan of one 32-bit value per lane with DPP moves (row shifts inside the rows of 16 lanes, then the
 // two row broadcasts): six VALU-speed steps.  __shfl_up goes through the LDS crossbar (ds_bpermute, ~100 cycles a
