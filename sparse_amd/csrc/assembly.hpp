@@ -42,17 +42,24 @@ __global__ __launch_bounds__(kBlock) void pack_coo_kernel(const int64_t *__restr
   keys[i] = k;
 }
 
-// The same for large inputs, with the counts of the keys' three top 8-bit digits (below bit end_bit) taken along the
-// way: when the assembly then sorts the top 16 or 24 bits by global passes (radix_sort_msd.hpp), those are the
-// histograms the passes start from, and the separate read of all keys for them (rs_hist_all) drops out (C2: 0.18 ms,
-// C5: 2 ms).  A fixed grid walks the input; one add per run of equal neighbouring digits as in rs_hist_all.
+// The same for large inputs, with digit histograms of the keys taken along the way: the digits of an LSD sort from bit
+// 0 and the (up to three) top-aligned digits the top-bits-first sort starts with (radix_sort_msd.hpp; the same digits
+// when the key width is a multiple of 8).  Whichever sort the assembly then picks finds its histograms made, and the
+// separate read of all keys for them (rs_hist_all: C2 0.18 ms, C5 2 ms, C3 1.3 ms) drops out.  A fixed grid walks
+// the input; one add per run of equal neighbouring digits as in rs_hist_all.
+constexpr int kPackDigitsMax = 12;
+struct PackDigits {
+  int n;
+  int shift[kPackDigitsMax], bits[kPackDigitsMax];
+};
+
 __global__ __launch_bounds__(kBlock) void pack_coo_hist_kernel(const int64_t *__restrict__ major,
                                                                const int64_t *__restrict__ minor, int64_t count,
                                                                int64_t n_major, int64_t n_minor, int minor_bits,
                                                                uint64_t *__restrict__ keys, int *__restrict__ err,
-                                                               int end_bit, uint32_t *__restrict__ ghist3) {
-  __shared__ uint32_t h[3][256];
-  for (int d = threadIdx.x; d < 3 * 256; d += kBlock) (&h[0][0])[d] = 0;
+                                                               PackDigits dg, uint32_t *__restrict__ ghist) {
+  __shared__ uint32_t h[kPackDigitsMax][256];
+  for (int d = threadIdx.x; d < dg.n * 256; d += kBlock) (&h[0][0])[d] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   bool bad = false;
@@ -66,11 +73,8 @@ __global__ __launch_bounds__(kBlock) void pack_coo_hist_kernel(const int64_t *__
       else k = shl_safe<uint64_t>((uint64_t)r, minor_bits) | (uint64_t)c;
       keys[i] = k;
     }
-#pragma unroll
-    for (int p = 0; p < 3; p++) {
-      const int shift = end_bit - 8 * (p + 1);
-      if (shift < 0) break;  // uniform
-      const uint32_t d = ok ? ((uint32_t)(k >> shift) & 255u) : 0xffffffffu;
+    for (int p = 0; p < dg.n; p++) {  // uniform
+      const uint32_t d = ok ? ((uint32_t)(k >> dg.shift[p]) & ((1u << dg.bits[p]) - 1u)) : 0xffffffffu;
       const uint32_t before = wave_prev_lane_dpp(d);
       const bool head = lane == 0 || d != before;
       const uint64_t hm = __ballot(head);
@@ -83,9 +87,9 @@ __global__ __launch_bounds__(kBlock) void pack_coo_hist_kernel(const int64_t *__
   }
   if (bad) *err = 1;
   __syncthreads();
-  for (int d = threadIdx.x; d < 3 * 256; d += kBlock) {
+  for (int d = threadIdx.x; d < dg.n * 256; d += kBlock) {
     const uint32_t v = (&h[0][0])[d];
-    if (v) atomicAdd(&ghist3[d], v);
+    if (v) atomicAdd(&ghist[d], v);
   }
 }
 
@@ -810,19 +814,33 @@ int assemble_coo(futhark_context *ctx, int64_t n_major, int64_t n_minor, const i
   SAMD_TRY(keys.get(count));
   for (int attempt = 0; attempt < 2; attempt++) {
     // large inputs whose sort may go the top-bits-first way (first attempt only): digit counts taken while packing
-    const bool with_hist = attempt == 0 && count >= kMsdMinCount && count < 0xffffffffLL && ctx->opt_sort_msd >= 0 &&
-                           ctx->opt_sort_algo == 0 && rbits + cbits >= 16;
+    const bool with_hist = attempt == 0 && count >= kMsdMinCount && count < 0xffffffffLL && ctx->opt_sort_algo == 0;
     if (count > 0 && with_hist) {
-      if (!hist3.p) SAMD_TRY(hist3.get(3 * 256));
-      SAMD_HIP(ctx, hipMemsetAsync(hist3.p, 0, sizeof(uint32_t) * 3 * 256, ctx->stream));
+      const int kb = rbits + cbits;
+      PackDigits dg;
+      dg.n = 0;
+      for (int sh = 0; sh < kb && dg.n < kPackDigitsMax; sh += 8) {  // the LSD sort's digits
+        dg.shift[dg.n] = sh;
+        dg.bits[dg.n++] = kb - sh < 8 ? kb - sh : 8;
+      }
+      for (int p = 1; p <= 3 && kb % 8 != 0 && kb - 8 * p >= 0 && dg.n < kPackDigitsMax; p++) {  // top-aligned ones
+        dg.shift[dg.n] = kb - 8 * p;
+        dg.bits[dg.n++] = 8;
+      }
+      if (!hist3.p) SAMD_TRY(hist3.get(kPackDigitsMax * 256));
+      SAMD_HIP(ctx, hipMemsetAsync(hist3.p, 0, sizeof(uint32_t) * kPackDigitsMax * 256, ctx->stream));
       const int64_t cap = (int64_t)ctx->num_cu * 16;
       hipLaunchKernelGGL(pack_coo_hist_kernel, dim3((unsigned)((int64_t)grid < cap ? (int64_t)grid : cap)), dim3(kBlock), 0,
-                         ctx->stream, major, minor, count, n_major, n_minor, cbits, keys.p, err.p, rbits + cbits, hist3.p);
+                         ctx->stream, major, minor, count, n_major, n_minor, cbits, keys.p, err.p, dg, hist3.p);
       SAMD_LAUNCH_CHECK(ctx);
       ctx->pre_hist = hist3.p;
       ctx->pre_hist_keys = keys.p;
       ctx->pre_hist_n = count;
-      ctx->pre_hist_end = rbits + cbits;
+      ctx->pre_digits = dg.n;
+      for (int d = 0; d < dg.n; d++) {
+        ctx->pre_shift[d] = dg.shift[d];
+        ctx->pre_bits[d] = dg.bits[d];
+      }
     } else if (count > 0) {
       hipLaunchKernelGGL((pack_coo_kernel<uint64_t>), dim3(grid), dim3(kBlock), 0, ctx->stream, major, minor, count,
                          n_major, n_minor, cbits, keys.p, err.p);

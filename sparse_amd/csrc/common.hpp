@@ -139,12 +139,12 @@ struct futhark_context {
   int64_t last_sort_msd = 0;       // top bits the last assembly's sort gave to the global passes (0 = plain LSD, -1 = tried, did not fit, sorted again)
   int64_t opt_noalloc_scratch_bytes = 0;  // tests: treat the static scratch array as this small (0 = its real size)
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
-  // digit histograms left by the pack kernel for the sort that follows (radix_sort.hpp: rs_take_pre_hist): counts of
-  // the three top-aligned 8-bit digits of pre_hist_keys[0 .. pre_hist_n) below bit pre_hist_end; null = none
-  uint32_t *pre_hist = nullptr;  // [3][256], index 0 = the top digit
+  // digit histograms left by the pack kernel for the sort that follows (radix_sort.hpp): pre_hist[d][256] = counts of
+  // bits [pre_shift[d], pre_shift[d] + pre_bits[d]) of pre_hist_keys[0 .. pre_hist_n); null = none
+  uint32_t *pre_hist = nullptr;
   const void *pre_hist_keys = nullptr;
   int64_t pre_hist_n = 0;
-  int pre_hist_end = 0;
+  int pre_digits = 0, pre_shift[12] = {0}, pre_bits[12] = {0};
   // statistics for futhark_context_report
   int64_t n_entries = 0;
   int64_t last_spmv_col_bytes = 0;  // bytes per column index the last SpMV kernel read (2, 4 or 8)

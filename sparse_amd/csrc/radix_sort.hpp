@@ -431,11 +431,18 @@ int radix_sort_pairs_onesweep(futhark_context *ctx, K *keys_a, K *keys_b, const 
   SAMD_HIP(ctx, hipMemsetAsync(ghist.p, 0, sizeof(uint32_t) * (size_t)gcount, ctx->stream));
   {
     // the kernel that packed these keys may have counted their top digits already (assembly.hpp: pack_coo_hist_kernel)
-    const bool pre = ctx->pre_hist != nullptr && ctx->pre_hist_keys == (const void *)keys_a && ctx->pre_hist_n == n &&
-                     ctx->pre_hist_end == end_bit && passes <= 3 && (end_bit - begin_bit) == 8 * passes;
+    int pre_idx[kRsMaxPasses];
+    bool pre = ctx->pre_hist != nullptr && ctx->pre_hist_keys == (const void *)keys_a && ctx->pre_hist_n == n;
+    for (int p = 0; pre && p < passes; p++) {
+      const int shift = begin_bit + 8 * p, nb = end_bit - shift < 8 ? end_bit - shift : 8;
+      pre_idx[p] = -1;
+      for (int d = 0; d < ctx->pre_digits; d++)
+        if (ctx->pre_shift[d] == shift && ctx->pre_bits[d] == nb) pre_idx[p] = d;
+      if (pre_idx[p] < 0) pre = false;
+    }
     if (pre) {
-      for (int p = 0; p < passes; p++)  // pass p sorts the digit at begin_bit + 8 p = top-aligned digit passes - 1 - p
-        SAMD_HIP(ctx, hipMemcpyAsync(ghist.p + p * kRsRadix, ctx->pre_hist + (passes - 1 - p) * kRsRadix,
+      for (int p = 0; p < passes; p++)
+        SAMD_HIP(ctx, hipMemcpyAsync(ghist.p + p * kRsRadix, ctx->pre_hist + pre_idx[p] * kRsRadix,
                                      sizeof(uint32_t) * kRsRadix, hipMemcpyDeviceToDevice, ctx->stream));
     } else {
       const int64_t cap = (int64_t)ctx->num_cu * 8;
