@@ -352,18 +352,9 @@ __global__ __launch_bounds__(kBlock) void fold_emit_kernel(const K *__restrict__
   }
   uint32_t total;
   block_scan_striped<uint32_t, OpAdd, kFoldItems>(v, 0u, OpAdd(), sh, total);  // v[j]: heads up to and including pair j
-  if (tid < 64) {  // wave 0: the tile's first output slot; the other waves fold their runs meanwhile
-    bool fail = false;
-    const unsigned long long off = (lab & 1) ? (unsigned long long)tile * kFoldTile : rl_lookback(status, tile, total, &fail);
-    if (tid == 0) {
-      if (fail) {
-        *err = 1;
-        s_fail = 1;
-      }
-      s_off = off;
-      if (!fail && tile + 1 == ntiles) *merged_out = off + total;
-    }
-  }
+  // wave 0 puts out the tile's count and requests its predecessors' status words; it looks at them after the fold
+  unsigned long long lb_words = 0;
+  if (tid < 64 && !(lab & 1)) lb_words = rl_publish(status, tile, total);
   // ---- fold: a run's first pair adds the rest of the run, left to right.  The second pair of a run is the next
   // lane's (same j): its value and the key behind it come by a lane shift, so the common run of two costs no load;
   // longer runs, and runs that start in lane 63, go on from global memory.  (With a global load per step, nearly
@@ -384,6 +375,18 @@ __global__ __launch_bounds__(kBlock) void fold_emit_kernel(const K *__restrict__
       if (q >= count || knext2 != k[j]) continue;
     }
     for (; q < count && keys[q] == k[j]; q++) val[j] = (T)(val[j] + vals_in[src(q)]);
+  }
+  if (tid < 64) {  // wave 0: the tile's first output slot
+    bool fail = false;
+    const unsigned long long off = (lab & 1) ? (unsigned long long)tile * kFoldTile : rl_finish(status, tile, total, lb_words, &fail);
+    if (tid == 0) {
+      if (fail) {
+        *err = 1;
+        s_fail = 1;
+      }
+      s_off = off;
+      if (!fail && tile + 1 == ntiles) *merged_out = off + total;
+    }
   }
   __syncthreads();
   if (s_fail) return;

@@ -223,24 +223,37 @@ constexpr int kRlTagBits = 13;
 // Look-back by one whole wavefront (all 64 lanes call it): 64 predecessors per step instead of one -- the first
 // 512 chunks of a launch start together and finish together, and a lane-by-lane walk over them was 0.25 ms of the
 // kernel on C2.  Returns the number of entries emitted by all earlier chunks; every lane gets it.
-__device__ __forceinline__ unsigned long long rl_lookback(unsigned long long *__restrict__ status, uint32_t chunk,
-                                                          unsigned long long mine_count, bool *fail) {
+// In two halves, so that the first round trip is in flight while the caller does something else: rl_publish puts
+// out this chunk's count and requests the status words of the 64 chunks before it; rl_finish (later, same wavefront)
+// starts from those words.  Device-scope loads take ~2 us under load, and a chunk that sat waiting for them kept its
+// workgroup's slot for nothing (C2: 0.49 of the in-LDS kernel's 1.67 ms went to the look-back).
+__device__ __forceinline__ unsigned long long rl_publish(unsigned long long *__restrict__ status, uint32_t chunk,
+                                                         unsigned long long mine_count) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long *mine = status + chunk;
+  if (lane == 0)
+    __hip_atomic_store(mine, (chunk == 0 ? kRsFlagIncl : kRsFlagAgg) | mine_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t t = (int64_t)chunk - 1 - lane;
+  return t >= 0 ? __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kRsFlagIncl;
+}
+
+__device__ __forceinline__ unsigned long long rl_finish(unsigned long long *__restrict__ status, uint32_t chunk,
+                                                        unsigned long long mine_count, unsigned long long first_words,
+                                                        bool *fail) {
   const int lane = threadIdx.x & 63;
   unsigned long long *mine = status + chunk;
   *fail = false;
-  if (chunk == 0) {
-    if (lane == 0) __hip_atomic_store(mine, kRsFlagIncl | mine_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return 0;
-  }
-  if (lane == 0) __hip_atomic_store(mine, kRsFlagAgg | mine_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (chunk == 0) return 0;
   unsigned long long excl = 0;
   int64_t top = (int64_t)chunk - 1;  // lane l looks at chunk top - l
   const unsigned long long t0 = wall_clock64();
-  bool bad = false;
+  bool bad = false, first = true;
   while (true) {
     const int64_t t = top - lane;
     unsigned long long w = kRsFlagIncl;  // before chunk 0: an inclusive prefix of nothing
-    if (t >= 0) w = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (first) w = first_words;
+    else if (t >= 0) w = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    first = false;
     const unsigned long long f = w >> 62;
     const uint64_t incl = __ballot(f == 2), pending = __ballot(f == 0), poison = __ballot(f == 3);
     // the nearest inclusive prefix, and everything nearer than it, must be there
@@ -264,6 +277,12 @@ __device__ __forceinline__ unsigned long long rl_lookback(unsigned long long *__
     else __hip_atomic_store(mine, kRsFlagIncl | (excl + mine_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return excl;
+}
+
+__device__ __forceinline__ unsigned long long rl_lookback(unsigned long long *__restrict__ status, uint32_t chunk,
+                                                          unsigned long long mine_count, bool *fail) {
+  const unsigned long long w = rl_publish(status, chunk, mine_count);
+  return rl_finish(status, chunk, mine_count, w, fail);
 }
 
 template <class T, class I, bool INDIRECT, int ITEMS, int DB>
@@ -468,18 +487,9 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
   }
   uint32_t U;
   const uint32_t uex = block_exclusive_add<uint32_t>(hc, shs, U);
-  if (tid < 64) {  // wave 0: the chunk's first output slot; the other waves fold their runs meanwhile
-    bool fail = false;
-    const unsigned long long off = (lab & 0x400) ? (unsigned long long)a : rl_lookback(status, chunk, U, &fail);
-    if (tid == 0) {
-      if (fail) {
-        *err = 1;
-        s_fail = 1;
-      }
-      s_off = off;
-      if (!fail && last_chunk) *merged_out = off + U;
-    }
-  }
+  // wave 0 puts out the chunk's count and requests its predecessors' status words; it looks at them after the fold
+  unsigned long long lb_words = 0;
+  if (tid < 64 && !(lab & 0x400)) lb_words = rl_publish(status, chunk, U);
   auto rl_key = [&](uint64_t id) -> uint64_t {  // the key a sorted composite (tag shifted out) stands for
     const uint64_t low = id & lowmask;
     return ((uint64_t)top_tab[(uint32_t)(id >> lowbits)] << tb) | ((low >> fb2) << fbits) | ((low & fmask2) + fmin);
@@ -523,6 +533,18 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
         endmask |= 1u << k;
         orow[k] = minor_bits >= 64 ? 0ull : (key >> minor_bits);
       }
+    }
+  }
+  if (tid < 64) {  // wave 0: the chunk's first output slot
+    bool fail = false;
+    const unsigned long long off = (lab & 0x400) ? (unsigned long long)a : rl_finish(status, chunk, U, lb_words, &fail);
+    if (tid == 0) {
+      if (fail) {
+        *err = 1;
+        s_fail = 1;
+      }
+      s_off = off;
+      if (!fail && last_chunk) *merged_out = off + U;
     }
   }
   __syncthreads();  // composites and payloads are spent; s_off is there
