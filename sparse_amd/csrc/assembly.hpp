@@ -157,6 +157,52 @@ __global__ __launch_bounds__(kBlock) void pack_csr_tile_kernel(const int64_t *__
   }
 }
 
+// The transposing form for large records, with the digit histograms the sort will start from taken along the way
+// (as pack_coo_hist_kernel does): a fixed grid walks the tiles.
+template <class K, class I>
+__global__ __launch_bounds__(kBlock) void pack_csr_tile_hist_kernel(const int64_t *__restrict__ row_ptr,
+                                                                    const I *__restrict__ col, int64_t nnz, int64_t ntiles,
+                                                                    const int64_t *__restrict__ tile_lb, int minor_bits,
+                                                                    K *__restrict__ keys, PackDigits dg,
+                                                                    uint32_t *__restrict__ ghist) {
+  __shared__ unsigned mark[4 * kBlock];
+  __shared__ unsigned sh[kWaves];
+  __shared__ uint32_t h[kPackDigitsMax][256];
+  for (int d = threadIdx.x; d < dg.n * 256; d += kBlock) (&h[0][0])[d] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int64_t row[4];
+    tile_rows(row_ptr, tile_lb, t, mark, sh, row);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t e = t * (4 * kBlock) + wave * 256 + k * 64 + lane;
+      const bool ok = e < nnz;
+      K key = 0;
+      if (ok) {
+        key = shl_safe<K>((K)col[e], minor_bits) | (K)row[k];
+        keys[e] = key;
+      }
+      for (int p = 0; p < dg.n; p++) {  // uniform
+        const uint32_t d = ok ? ((uint32_t)(key >> dg.shift[p]) & ((1u << dg.bits[p]) - 1u)) : 0xffffffffu;
+        const uint32_t before = wave_prev_lane_dpp(d);
+        const bool head = lane == 0 || d != before;
+        const uint64_t hm = __ballot(head);
+        if (head && ok) {
+          const uint64_t rest = lane == 63 ? 0ull : (hm >> (lane + 1));
+          atomicAdd(&h[p][d], rest ? (uint32_t)__builtin_ctzll(rest) + 1u : (uint32_t)(64 - lane));
+        }
+      }
+    }
+    __syncthreads();  // tile_rows' LDS is reused by the next tile
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < dg.n * 256; d += kBlock) {
+    const uint32_t v = (&h[0][0])[d];
+    if (v) atomicAdd(&ghist[d], v);
+  }
+}
+
 // key of stored entry e: (row << minor_bits | col), or swapped (col << minor_bits | row)
 template <class K, class I, bool SWAP>
 __global__ __launch_bounds__(kBlock) void pack_csr_kernel(const int64_t *__restrict__ row_ptr,
@@ -905,10 +951,46 @@ int transpose_physical(futhark_context *ctx, const CsrBody<T> *a, CsrBody<T> **o
                                       out, false, false, true);
   }
   Tmp<uint64_t> keys(ctx);
+  Tmp<uint32_t> hist(ctx);
   SAMD_TRY(keys.get(a->nnz));
-  SAMD_TRY((pack_csr<uint64_t, T, true>(ctx, a, rbits, keys.p)));
-  return assemble_core<uint64_t, T>(ctx, keys, a->nnz, rbits, rbits + cbits, rbits, a->vals, a->m, a->n, nullptr, out,
-                                    false, false, true);
+  const int passes = (cbits + 7) / 8;
+  if (a->nnz >= kMsdMinCount && a->nnz < 0xffffffffLL && a->tile == 4 * kBlock && a->n < 0x7fffffffLL && ctx->opt_sort_algo == 0 &&
+      passes <= kPackDigitsMax) {
+    // large record: the column digits are counted while the keys are packed (the sort's own histogram pass drops out)
+    PackDigits dg;
+    dg.n = 0;
+    for (int sh = rbits; sh < rbits + cbits; sh += 8) {
+      dg.shift[dg.n] = sh;
+      dg.bits[dg.n++] = rbits + cbits - sh < 8 ? rbits + cbits - sh : 8;
+    }
+    SAMD_TRY(hist.get(kPackDigitsMax * 256));
+    SAMD_HIP(ctx, hipMemsetAsync(hist.p, 0, sizeof(uint32_t) * kPackDigitsMax * 256, ctx->stream));
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    const unsigned grid = (unsigned)(a->ntiles < cap ? a->ntiles : cap);
+    if (a->col32)
+      hipLaunchKernelGGL((pack_csr_tile_hist_kernel<uint64_t, int32_t>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                         (const int64_t *)a->row_ptr, (const int32_t *)a->col32, a->nnz, a->ntiles, (const int64_t *)a->tile_lb,
+                         rbits, keys.p, dg, hist.p);
+    else
+      hipLaunchKernelGGL((pack_csr_tile_hist_kernel<uint64_t, int64_t>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                         (const int64_t *)a->row_ptr, (const int64_t *)a->col64, a->nnz, a->ntiles, (const int64_t *)a->tile_lb,
+                         rbits, keys.p, dg, hist.p);
+    SAMD_LAUNCH_CHECK(ctx);
+    ctx->pre_hist = hist.p;
+    ctx->pre_hist_keys = keys.p;
+    ctx->pre_hist_n = a->nnz;
+    ctx->pre_digits = dg.n;
+    for (int d = 0; d < dg.n; d++) {
+      ctx->pre_shift[d] = dg.shift[d];
+      ctx->pre_bits[d] = dg.bits[d];
+    }
+  } else {
+    SAMD_TRY((pack_csr<uint64_t, T, true>(ctx, a, rbits, keys.p)));
+  }
+  const int rc = assemble_core<uint64_t, T>(ctx, keys, a->nnz, rbits, rbits + cbits, rbits, a->vals, a->m, a->n, nullptr, out,
+                                            false, false, true);
+  ctx->pre_hist = nullptr;
+  return rc;
 }
 
 // sr.+ / sr.- : (coo a ++ coo (scale -1 b)) |> sparse n m  (compressed.fut:179-183)
