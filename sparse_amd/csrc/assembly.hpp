@@ -229,13 +229,13 @@ __global__ __launch_bounds__(kBlock) void concat_vals_kernel(const T *__restrict
 // pairs of |i - key[i] / keyspace * count| (the rank a key would have if keys were spread evenly), each
 // capped at `cap`.  Small for inputs that are sorted, nearly sorted, or a banded record being transposed
 // (key = column, position ~ row): the final gather vals[perm[i]] then stays inside a cache-sized window.
-template <class K>
-__global__ __launch_bounds__(kBlock) void displacement_sample_kernel(const K *__restrict__ keys, int64_t count,
+template <class KF>
+__global__ __launch_bounds__(kBlock) void displacement_sample_kernel(KF keys, int64_t count,
                                                                      double inv_keyspace, unsigned long long cap,
                                                                      unsigned long long *__restrict__ out) {
   const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x, total = (int64_t)gridDim.x * kBlock;
   const int64_t i = (count - 1) / total * s;
-  const double pred = (double)keys[i] * inv_keyspace * (double)count;
+  const double pred = (double)keys(i) * inv_keyspace * (double)count;
   const double d = fabs(pred - (double)i);
   unsigned long long v = d >= (double)cap ? cap : (unsigned long long)d;
   v = wave_reduce(v, OpAdd());
@@ -552,11 +552,12 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     bool indirect = sizeof(T) > 4;
     if (sizeof(T) > 4 && ctx->opt_sort_indirect < 0) indirect = false;
     const bool sample_far = sorted_runs_split < 0 && sizeof(T) > 4 && ctx->opt_sort_indirect == 0 && count >= (1 << 20) && end_bit - begin_bit > 16;
-    if (sample_far) {
+    const bool presampled = ctx->pre_sample && ctx->pre_sample_n == count && ctx->pre_sample_end == end_bit && begin_bit == 0;
+    if (sample_far && !presampled) {
       SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 8, 0, sizeof(int64_t), ctx->stream));
       const double keyspace = ldexp((double)(n_major > 0 ? n_major : 1), minor_bits);
       const unsigned long long cap = (unsigned long long)count;
-      hipLaunchKernelGGL((displacement_sample_kernel<K>), dim3(16), dim3(kBlock), 0, ctx->stream, (const K *)keys.p,
+      hipLaunchKernelGGL((displacement_sample_kernel<KeyArr<K>>), dim3(16), dim3(kBlock), 0, ctx->stream, KeyArr<K>{keys.p},
                          count, 1.0 / keyspace, cap, reinterpret_cast<unsigned long long *>(ctx->d_small + 8));
       SAMD_LAUNCH_CHECK(ctx);
     }
@@ -574,6 +575,10 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
       if (msd_tb > 38) msd_tb = -1;  // composite = ordinal (<= 12 bits) | low bits | 13-bit tag, in 64 bits
     }
     if (sample_far) {
+      if (far < 0 && presampled) {
+        SAMD_HIP(ctx, hipEventSynchronize(ctx->ev_pre));
+        far = ctx->h_small[12];
+      }
       if (far < 0) SAMD_TRY(read_small(ctx, ctx->d_small + 8, 1, &far));
       const double mean = (double)far / (16.0 * kBlock);
       indirect = mean * sizeof(T) <= (double)(1 << 20);
@@ -864,6 +869,25 @@ int assemble_coo(futhark_context *ctx, int64_t n_major, int64_t n_minor, const i
   for (int attempt = 0; attempt < 2; attempt++) {
     // large inputs whose sort may go the top-bits-first way (first attempt only): digit counts taken while packing
     const bool with_hist = attempt == 0 && count >= kMsdMinCount && count < 0xffffffffLL && ctx->opt_sort_algo == 0;
+    if (count > 0 && with_hist && ctx->opt_sort_msd == 0 && rbits + cbits >= 16 && rbits + cbits <= 64 - kRlTagBits) {
+      // The samples the sort's choice rests on (top 16 key bits; distance from the sorted place) are taken from the
+      // triples BEFORE the keys are packed and sent to the host behind an event: the host waits for them, decides
+      // and queues the sort while the pack kernel runs, instead of leaving the GPU idle while it does (~0.2 ms on C2).
+      const KeyCoo kc{major, minor, n_major, n_minor, cbits};
+      SAMD_TRY(msd_launch_samples(ctx, kc, count, rbits + cbits));
+      SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 8, 0, sizeof(int64_t), ctx->stream));
+      if (sizeof(T) > 4) {
+        const double keyspace = ldexp((double)(n_major > 0 ? n_major : 1), cbits);
+        hipLaunchKernelGGL((displacement_sample_kernel<KeyCoo>), dim3(16), dim3(kBlock), 0, ctx->stream, kc, count,
+                           1.0 / keyspace, (unsigned long long)count, reinterpret_cast<unsigned long long *>(ctx->d_small + 8));
+        SAMD_LAUNCH_CHECK(ctx);
+      }
+      SAMD_HIP(ctx, hipMemcpyAsync(ctx->h_small + 8, ctx->d_small + 4, sizeof(int64_t) * 5, hipMemcpyDeviceToHost, ctx->stream));
+      SAMD_HIP(ctx, hipEventRecord(ctx->ev_pre, ctx->stream));
+      ctx->pre_sample = true;
+      ctx->pre_sample_n = count;
+      ctx->pre_sample_end = rbits + cbits;
+    }
     if (count > 0 && with_hist) {
       const int kb = rbits + cbits;
       PackDigits dg;
@@ -901,6 +925,7 @@ int assemble_coo(futhark_context *ctx, int64_t n_major, int64_t n_minor, const i
     const int rc = assemble_core<uint64_t, T>(ctx, keys, count, 0, rbits + cbits, cbits, vals, n_major, n_minor, err.p,
                                               out, attempt == 0, attempt == 0);
     ctx->pre_hist = nullptr;
+    ctx->pre_sample = false;
     ctx->sort_force_scan = false;
     if (attempt == 1) ctx->last_sort_msd = -1;  // tried, sorted again
     if (rc != kAssembleAgain) return rc;

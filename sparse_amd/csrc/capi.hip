@@ -607,7 +607,8 @@ struct futhark_context *futhark_context_new(struct futhark_context_config *cfg) 
   if (hipSetDevice(ctx->device) != hipSuccess || hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_small, sizeof(int64_t) * 16, hipHostMallocDefault) != hipSuccess ||
-      hipMalloc((void **)&ctx->d_small, sizeof(int64_t) * 16) != hipSuccess) {
+      hipMalloc((void **)&ctx->d_small, sizeof(int64_t) * 16) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_pre, hipEventDisableTiming) != hipSuccess) {
     set_error(ctx, "context initialisation failed: %s", hipGetErrorString(hipGetLastError()));
     return ctx;
   }
@@ -636,6 +637,7 @@ void futhark_context_free(struct futhark_context *ctx) {
     ctx->pool.clear();
     (void)hipFree(ctx->d_small);
     (void)hipHostFree(ctx->h_small);
+    if (ctx->ev_pre) (void)hipEventDestroy(ctx->ev_pre);
     (void)hipStreamDestroy(ctx->own_stream);
   }
   delete ctx;

@@ -141,6 +141,13 @@ struct futhark_context {
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
   // digit histograms left by the pack kernel for the sort that follows (radix_sort.hpp): pre_hist[d][256] = counts of
   // bits [pre_shift[d], pre_shift[d] + pre_bits[d]) of pre_hist_keys[0 .. pre_hist_n); null = none
+  // samples of the keys taken BEFORE the keys were packed (assembly.hpp: the host then waits for them on ev_pre while
+  // the pack kernel runs, instead of idling the GPU while it decides): valid for pre_sample_n keys ending at bit
+  // pre_sample_end; the five words land in h_small[8 .. 13)
+  hipEvent_t ev_pre = nullptr;
+  bool pre_sample = false;
+  int64_t pre_sample_n = 0;
+  int pre_sample_end = 0;
   uint32_t *pre_hist = nullptr;
   const void *pre_hist_keys = nullptr;
   int64_t pre_hist_n = 0;

@@ -44,15 +44,32 @@ constexpr int64_t kMsdSamples = 1 << 21;
 __host__ __device__ inline bool msd_gate_skewed(unsigned long long mx, unsigned long long used) {
   return used == 0 || mx * used > 32ull * used + 4ull * 32768ull;
 }
+// where a sampled key comes from: the packed array, or the triples it will be packed from
 template <class K>
-__global__ __launch_bounds__(kBlock) void msd_sample_kernel(const K *__restrict__ keys, int64_t count, int64_t stride,
+struct KeyArr {
+  const K *k;
+  __device__ __forceinline__ K operator()(int64_t i) const { return k[i]; }
+};
+struct KeyCoo {
+  const int64_t *major, *minor;
+  int64_t n_major, n_minor;
+  int minor_bits;
+  __device__ __forceinline__ uint64_t operator()(int64_t i) const {
+    const int64_t r = major[i], c = minor[i];
+    if (r < 0 || r >= n_major || c < 0 || c >= n_minor) return 0;  // as pack_coo_kernel stores it (the assembly fails later)
+    return (minor_bits >= 64 ? 0ull : ((uint64_t)r << minor_bits)) | (uint64_t)c;
+  }
+};
+
+template <class KF>
+__global__ __launch_bounds__(kBlock) void msd_sample_kernel(KF keys, int64_t count, int64_t stride,
                                                             int shift, uint32_t *__restrict__ hist,
                                                             const unsigned long long *__restrict__ gate) {
   if (gate && msd_gate_skewed(gate[0], gate[1])) return;
   const int64_t total = (int64_t)gridDim.x * kBlock;
   const int lane = threadIdx.x & 63;
   for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s * stride < count; s += total) {
-    const uint32_t bin = (uint32_t)(keys[s * stride] >> shift) & (uint32_t)(kMsdBins - 1);
+    const uint32_t bin = (uint32_t)(keys(s * stride) >> shift) & (uint32_t)(kMsdBins - 1);
     // sorted inputs put a whole wavefront into one bin: one add for all of them
     const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
     const uint64_t active = __ballot(true), same = __ballot(bin == first);
@@ -81,6 +98,32 @@ __global__ __launch_bounds__(kBlock) void msd_max_kernel(const uint32_t *__restr
   }
 }
 
+// The two samples of the top 16 key bits (d_small[4 .. 8) = [max, used, gate max, gate used]); no synchronisation.
+template <class KF>
+int msd_launch_samples(futhark_context *ctx, KF keys, int64_t count, int end_bit) {
+  Tmp<uint32_t> hist(ctx);
+  SAMD_TRY(hist.get(2 * kMsdBins));
+  SAMD_HIP(ctx, hipMemsetAsync(hist.p, 0, sizeof(uint32_t) * 2 * kMsdBins, ctx->stream));
+  SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 4, 0, 4 * sizeof(int64_t), ctx->stream));
+  unsigned long long *res = reinterpret_cast<unsigned long long *>(ctx->d_small + 4);
+  const int64_t stride = cdiv(count, kMsdSamples);
+  const int64_t samples = cdiv(count, stride);
+  // a small sample first; the full one runs only if that one is even
+  const int64_t gstride = cdiv(count, (int64_t)1 << 15);
+  hipLaunchKernelGGL((msd_sample_kernel<KF>), dim3((unsigned)cdiv(cdiv(count, gstride), kBlock)), dim3(kBlock), 0,
+                     ctx->stream, keys, count, gstride, end_bit - 16, hist.p + kMsdBins, (const unsigned long long *)nullptr);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(msd_max_kernel, dim3(64), dim3(kBlock), 0, ctx->stream, (const uint32_t *)(hist.p + kMsdBins), res + 2);
+  SAMD_LAUNCH_CHECK(ctx);
+  const int64_t want = cdiv(samples, kBlock), capg = (int64_t)ctx->num_cu * 16;
+  hipLaunchKernelGGL((msd_sample_kernel<KF>), dim3((unsigned)(want < capg ? want : capg)), dim3(kBlock), 0, ctx->stream,
+                     keys, count, stride, end_bit - 16, hist.p, (const unsigned long long *)(res + 2));
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(msd_max_kernel, dim3(64), dim3(kBlock), 0, ctx->stream, (const uint32_t *)hist.p, res);
+  SAMD_LAUNCH_CHECK(ctx);
+  return 0;  // (hist goes back to the pool here; whatever takes it next runs behind these kernels on the same stream)
+}
+
 // Chooses the number of top bits the global passes take (*tb = first of them; -1 = keep the LSD sort) and the
 // nominal chunk length.  One small read-back.
 template <class K>
@@ -104,32 +147,17 @@ int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit
     return 0;
   }
   if (count < kMsdMinCount || total <= 24 || end_bit < 16) return 0;
-  Tmp<uint32_t> hist(ctx);
-  SAMD_TRY(hist.get(2 * kMsdBins));
-  SAMD_HIP(ctx, hipMemsetAsync(hist.p, 0, sizeof(uint32_t) * 2 * kMsdBins, ctx->stream));
-  SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small + 4, 0, 4 * sizeof(int64_t), ctx->stream));
-  unsigned long long *res = reinterpret_cast<unsigned long long *>(ctx->d_small + 4);  // [max, used, gate max, gate used]
+  int64_t h[5];
   const int64_t stride = cdiv(count, kMsdSamples);
   const int64_t samples = cdiv(count, stride);
-  {
-    // a small sample first; the full one runs only if that one is even
-    const int64_t gstride = cdiv(count, (int64_t)1 << 15);
-    hipLaunchKernelGGL((msd_sample_kernel<K>), dim3((unsigned)cdiv(cdiv(count, gstride), kBlock)), dim3(kBlock), 0,
-                       ctx->stream, keys, count, gstride, end_bit - 16, hist.p + kMsdBins,
-                       (const unsigned long long *)nullptr);
-    SAMD_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(msd_max_kernel, dim3(64), dim3(kBlock), 0, ctx->stream, (const uint32_t *)(hist.p + kMsdBins),
-                       res + 2);
-    SAMD_LAUNCH_CHECK(ctx);
-    const int64_t want = cdiv(samples, kBlock), capg = (int64_t)ctx->num_cu * 16;
-    hipLaunchKernelGGL((msd_sample_kernel<K>), dim3((unsigned)(want < capg ? want : capg)), dim3(kBlock), 0, ctx->stream,
-                       keys, count, stride, end_bit - 16, hist.p, (const unsigned long long *)(res + 2));
-    SAMD_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(msd_max_kernel, dim3(64), dim3(kBlock), 0, ctx->stream, (const uint32_t *)hist.p, res);
-    SAMD_LAUNCH_CHECK(ctx);
+  if (ctx->pre_sample && ctx->pre_sample_n == count && ctx->pre_sample_end == end_bit && begin_bit == 0) {
+    // taken from the triples before they were packed: the words are on their way (or there) while the pack kernel runs
+    SAMD_HIP(ctx, hipEventSynchronize(ctx->ev_pre));
+    for (int i = 0; i < 5; i++) h[i] = ctx->h_small[8 + i];
+  } else {
+    SAMD_TRY(msd_launch_samples(ctx, KeyArr<K>{keys}, count, end_bit));
+    SAMD_TRY(read_small(ctx, ctx->d_small + 4, 5, h));
   }
-  int64_t h[5];
-  SAMD_TRY(read_small(ctx, ctx->d_small + 4, 5, h));
   if (slot8) *slot8 = h[4];
   if (msd_gate_skewed((unsigned long long)h[2], (unsigned long long)h[3]) || h[1] <= 0) return 0;  // skewed at first sight
   const double per_sample = (double)count / (double)samples;
