@@ -629,6 +629,12 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
         }
         if (err_flag)
           SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 1, err_flag, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        // the row ends' max-scan needs nothing from the host: queued before the read-back so that it runs while the
+        // host waits (wasted, harmlessly, if the assembly is repeated)
+        if (n_major > 0)
+          SAMD_TRY((device_scan<int64_t, OpMax, PtrIn<int64_t>, false>(ctx, PtrIn<int64_t>{b->row_ptr + 1}, n_major,
+                                                                        (int64_t)0, OpMax(), b->row_ptr + 1,
+                                                                        (int64_t *)nullptr)));
         int64_t host[4];
         SAMD_TRY(read_small(ctx, ctx->d_small, 4, host));
         if (ctx->opt_sort_inject && allow_retry) host[2] = 1;
@@ -664,10 +670,6 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
             b->col64 = c2;
           }
         }
-        if (n_major > 0)
-          SAMD_TRY((device_scan<int64_t, OpMax, PtrIn<int64_t>, false>(ctx, PtrIn<int64_t>{b->row_ptr + 1}, n_major,
-                                                                        (int64_t)0, OpMax(), b->row_ptr + 1,
-                                                                        (int64_t *)nullptr)));
         SAMD_TRY(build_plan(ctx, b));
         *out = guard.release();
         return 0;
