@@ -721,11 +721,12 @@ def _banded_with_holes(n, hb, dtype, seed):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("k", [64, 16, 40, 130])
+@pytest.mark.parametrize("k", [64, 16, 40, 130, 8, 48, 3])
 def test_smm_matrix_core_tiles(ctx, dtype, k):
     """Banded tiles with long rows take the dense-block (MFMA) path of spmm_stream; the same record with
     spmm_algo 3 never does.  Both against the oracle, on a band with empty rows, thinned rows, rows crossing
-    tile ends and a row longer than a tile (whose tiles cannot use the dense block)."""
+    tile ends and a row longer than a tile (whose tiles cannot use the dense block); panels narrower than one
+    wavefront's 16 columns and panels that are not a multiple of 16 among them."""
     O, M = Oracle(dtype), mk(ctx, dtype)
     for n, hb in ((5000, 13), (3000, 30), (777, 9)):
         r, c, v = _banded_with_holes(n, hb, dtype, seed=70 + hb)
@@ -742,12 +743,13 @@ def test_smm_matrix_core_tiles(ctx, dtype, k):
             ctx.set_option("spmm_algo", 0)
 
 
+@pytest.mark.parametrize("k", [64, 24])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_smm_matrix_core_tiles_keep_nonfinite_rows_of_B_local(ctx, dtype):
+def test_smm_matrix_core_tiles_keep_nonfinite_rows_of_B_local(ctx, dtype, k):
     """The dense block is zero-filled; 0 * inf must not leak into rows that do not reference the row of B
     holding the inf / nan: same pattern of non-finite results as the oracle, finite values within tolerance."""
     O, M = Oracle(dtype), mk(ctx, dtype)
-    n, hb, k = 4000, 13, 64
+    n, hb = 4000, 13
     r, c, v = synth.banded_coo(n, hb, dtype)
     keep = ~((c == 1000) & (r != 1003)) & ~((c == 2500) & (r % 2 == 0))   # column 1000 referenced by one row only
     r, c, v = r[keep], c[keep], v[keep]
@@ -755,7 +757,7 @@ def test_smm_matrix_core_tiles_keep_nonfinite_rows_of_B_local(ctx, dtype):
     B = synth.uniform_values(72, n * k, dtype).reshape(n, k).copy()
     B[1000, :] = np.inf
     B[2500, 7] = np.nan
-    B[2500, 40] = -np.inf
+    B[2500, 40 if k > 40 else 19] = -np.inf
     with np.errstate(invalid="ignore"):
         want = O.sr_smm(Ao, B)
     got = M.sr.smm(A, B).numpy()
