@@ -225,6 +225,41 @@ def test_c3_two_pass_product_is_chosen_and_within_tolerance():
     assert torch.equal(yi, yi2)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_large_assembly_reports_an_out_of_range_index_and_recovers(dtype):
+    """6e6 triples (large enough for the path that samples the triples before packing them, counts digits while
+    packing and sorts the top key bits first): one row index equal to n, then one negative column, must fail with
+    the reference's bounds message whichever kernels ran; the same context then assembles the clean input, and that
+    record equals the one the plain LSD sort builds."""
+    torch, ctx = _ctx()
+    from sparse_amd import mk_compressed
+    from sparse_amd.compressed import SparseError
+    M = mk_compressed(dtype, ctx)
+    n = m = 3 * 10**6
+    k = 6 * 10**6
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(11)
+    r = torch.randint(0, n, (k,), generator=g, device="cuda:0", dtype=torch.int64)
+    c = torch.randint(0, m, (k,), generator=g, device="cuda:0", dtype=torch.int64)
+    v = (torch.rand(k, generator=g, device="cuda:0", dtype=torch.float64) + 0.5).to(
+        torch.float64 if dtype == "f64" else torch.float32)
+    for arr, pos, bad in ((r, 4321, n), (c, k - 7, -1)):
+        keep = int(arr[pos])
+        arr[pos] = bad
+        with pytest.raises(SparseError, match="out of bounds"):
+            M.sr.sparse(n, m, (r, c, v))
+        arr[pos] = keep
+    A = M.sr.sparse(n, m, (r, c, v))
+    assert ctx.get_option("sort_last_msd") > 0
+    ctx.set_option("sort_msd", -1)
+    try:
+        B = M.sr.sparse(n, m, (r, c, v))
+    finally:
+        ctx.set_option("sort_msd", 0)
+    for fa, fb in zip(A.fields(), B.fields()):
+        assert torch.equal(torch.as_tensor(fa, device="cuda:0"), torch.as_tensor(fb, device="cuda:0"))
+
+
 def test_skewed_f64_record_takes_the_folded_two_pass_product():
     """RMAT scale 22 with 8-byte values: the lines of columns are sorted into the blocks by popularity and pass 1 adds
     up what a row holds in a piece, which is what makes two passes pay for 8-byte values (scale 24: 2.45 -> 1.46 ms).
