@@ -123,6 +123,7 @@ struct futhark_context {
                                                                                  // 32-column lines per block, entries per panel
   int64_t opt_spmv_pb_fold = 0;  // two-pass SpMV, products of one row inside one piece summed in pass 1: 0 when it shortens the product stream by >= 15 %, 1 always, -1 never
   int64_t opt_spmv_pb_deal = 0;    // lines into column blocks: 0 sorted by popularity for skewed records (with the folded layout), dealt round otherwise; 1 always sorted; -1 always dealt
+  int64_t opt_spmv_pb_shares = 0;  // lab: folded layout, pass 1's workgroups per CU (0 = 4)
   int64_t opt_spmv_pb_oround = 0;  // lab: folded layout, alignment of a piece's outputs in products (0 = kPbOutRound)
   int64_t last_pb_fold = 0;      // 1 if the last two-pass product ran on a folded layout; last_pb_outputs: products it wrote (pads included)
   int64_t last_pb_outputs = 0;

@@ -890,7 +890,7 @@ int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, co
   std::vector<int64_t> wt;
   {
     constexpr int64_t kStep = (int64_t)kPbThreads * 8;  // pb_pass1f_kernel<T, 8>
-    const int64_t target = (int64_t)ctx->num_cu * 4;
+    const int64_t target = (int64_t)ctx->num_cu * (ctx->opt_spmv_pb_shares > 0 ? ctx->opt_spmv_pb_shares : 4);
     const int64_t total = hb[(size_t)nb] - hb[0] > 0 ? hb[(size_t)nb] - hb[0] : 1;
     for (int64_t b = 0; b < nb; b++) {
       const int64_t s0 = hb[(size_t)b], e0 = hb[(size_t)b + 1];
