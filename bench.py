@@ -5,19 +5,31 @@ Headline leg (`value`, `ms_per_step`, `roofline`): the 5-point Laplacian of a 40
 (BASELINE configs[1]).  One "step" = one y = A x over the whole matrix (all ranks).  The matrix is built
 through the product path itself (shuffled COO -> sr.sparse on the device); x and the matrix are resident in
 HBM before the timed region; a step allocates nothing (sparse_amd_csr_f64_smvm_into on handles made once).
+The bench says what it is -- a loop of many products -- through sparse_amd_csr_f64_prepare, so the record's
+16-bit index arrays are built before the first step instead of at the 16th product.
+Order of the headline leg, and what each number is:
+  parity gate (1 product) -> W warm-up steps -> the K timed steps = `ms_per_step`, `value`, `roofline`
+  (exactly what the driver asked for: `warmup` is W, nothing else runs before the timed region)
+  -> K more steps with an event after every step = `roofline.kernel_ms_median`
+  -> the bit-reproducibility gate (SETTLE untimed products that must give the same bits)
+  -> K timed steps again = the `settled` object (a card that has been busy for ~0.1 s; the figure a solver sees).
 N > 1 (one process per GPU, torch.distributed over RCCL): weak scaling -- rank k owns the k-th block of
 4096*4096 rows of the (N*4096) x 4096 grid's matrix and the matching slice of x; each step exchanges the x
 entries other ranks need (sparse_amd.distributed: halo transfers overlapped with the owned-column block),
 then runs the same SpMV kernel on its rows.
 
-Second leg (`c5` object of the same JSON line; --no-c5 skips it): what north_star scales on -- BASELINE
-configs[4], COO -> CSR assembly + SpMV of a 10^9-triple uniform random 1e7 x 1e7 f64 matrix, STRONG scaling:
-the same global matrix at every N.  Each rank generates 1/N of the triple list from the counter PRNG
-(synth.random_uniform_coo_counter_device), the ranks exchange triples so that each owns a row block
-(DistCsr.from_coo_chunks: one all-to-all-v, then the single-GPU assembly), every step all-gathers x over
-RCCL and multiplies.  Parity gate on integer-valued data (sums exact in any order): y equals torch's own
-scatter-add of the generated triples, bit for bit, on every rank.  Assembly, the exchange alone and the
-kernel alone are timed separately.
+Further legs in the same JSON line (N = 1 only unless said; --no-legs skips c3 / c4, --no-c5 skips c5):
+  `c3`  BASELINE configs[2]: RMAT scale 24, edge factor 18, f32 -- assembly + SpMV (the power-law target);
+        parity: y against torch's own f64 scatter-add of the generated triples.
+  `c4`  BASELINE configs[3]: banded n = 2^20, 27 per row, times a dense [n][64] f64 panel (SpMM); parity:
+        columns of C against smvm on the same columns of B (the build-defined oracle).
+  `c5`  BASELINE configs[4], every N, STRONG scaling: COO -> CSR assembly + SpMV of a 10^9-triple uniform random
+        1e7 x 1e7 f64 matrix, the same global matrix at every N.  Each rank generates 1/N of the triple list from
+        the counter PRNG (synth.random_uniform_coo_counter_device), the ranks exchange triples so that each owns
+        a row block (DistCsr.from_coo_chunks: one all-to-all-v, then the single-GPU assembly), every step
+        all-gathers x over RCCL and multiplies.  Parity on integer-valued data (sums exact in any order): y equals
+        torch's own scatter-add of the generated triples, bit for bit, on every rank.  Assembly, the exchange
+        alone and the kernel alone are timed separately.
 
 Prints ONE JSON line on rank 0.
 """
@@ -51,7 +63,7 @@ def laplacian_csr_host(g):
             "vals": np.ascontiguousarray(vals)}
 
 
-def cpu_baseline(g, seconds=12.0):
+def cpu_baseline(g, seconds=10.0):
     """The oracle's SpMV (a port of compressed.fut:134-146, rows over OpenMP threads) timed on this host on
     the bench's own matrix (the 4096^2 stencil), a bounded number of products."""
     import numpy as np
@@ -94,6 +106,150 @@ def timed_steps(torch, dist, fn, steps):
     return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
 
 
+def per_step_ms(torch, fn, steps):
+    """An event after every step on torch's current stream (the stream the context has adopted): the list of
+    per-step device times, for the median BASELINE.md asks for."""
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record()
+    for i in range(steps):
+        fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    return [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def median(xs):
+    xs = sorted(xs)
+    k = len(xs)
+    return xs[k // 2] if k % 2 else 0.5 * (xs[k // 2 - 1] + xs[k // 2])
+
+
+def measured_ceilings(ctx, read_per_group, write_per_group, groups):
+    """The card's own ceilings, measured now in this process (sparse_amd_context_measure_bandwidth: no arithmetic,
+    128-bit non-temporal loads and stores): a pure read, a pure write, a copy, and the kernel's own mix."""
+    out = {}
+    for name, rd, wr, g in (("read", 16384, 0, 65536), ("write", 0, 16384, 65536), ("copy", 16384, 16384, 32768),
+                            ("kernel_mix", read_per_group, write_per_group, groups)):
+        gbs, us = ctx.measure_bandwidth(rd, wr, g)
+        out[name] = {"GBs": round(gbs, 1), "us": round(us, 2), "read_bytes_per_group": rd, "write_bytes_per_group": wr, "groups": g}
+    return out
+
+
+def c3_leg(args, torch, dev, ctx):
+    """BASELINE configs[2]: RMAT scale 24, edge factor 18, f32 -- assembly and SpMV on one GPU."""
+    from sparse_amd import mk_compressed, synth
+    n = 1 << args.c3_scale
+    M = mk_compressed("f32", ctx)
+    r, c, v = synth.rmat_coo_device(args.c3_scale, 18, dev, "f32")
+    nnz0 = r.numel()
+    A = M.sr.sparse(n, n, (r, c, v))                # once untimed: pool and code objects
+    del A
+    ctx.sync()
+    t0 = time.perf_counter()
+    A = M.sr.sparse(n, n, (r, c, v))
+    ctx.sync()
+    asm_ms = (time.perf_counter() - t0) * 1e3
+    nnz = A.stored_dims()[2]
+    x = torch.rand(n, device=dev, dtype=torch.float32) + 0.5
+    y = torch.empty(n, device=dev, dtype=torch.float32)
+    xh, yh = ctx.array(x, "f32"), ctx.array(y, "f32")
+    t0 = time.perf_counter()
+    M.sr.smvm_into(yh, A, xh)                       # product 1 of a record nobody has said anything about:
+    ctx.sync()                                      # nothing is built, the one-pass kernel on the record as assembled
+    first_ms = (time.perf_counter() - t0) * 1e3
+    first_path = ctx.get_option("spmv_last_path")
+    t0 = time.perf_counter()
+    M.sr.prepare(A, 1 << 20)                        # "many products follow": the two-pass copy is built here
+    ctx.sync()
+    prep_ms = (time.perf_counter() - t0) * 1e3
+    M.sr.smvm_into(yh, A, xh)
+    path = ctx.get_option("spmv_last_path")
+    # parity gate: torch's own scatter-add of the generated triples, in f64
+    want = torch.zeros(n, device=dev, dtype=torch.float64).index_add_(0, r, v.double() * x.double()[c])
+    nz = want > 0
+    rel = float(((y.double() - want).abs()[nz] / want[nz]).max())
+    assert rel <= 1e-5, "C3 leg: SpMV differs from the f64 scatter-add of the generated triples by %g" % rel
+    del want, nz, r, c, v
+    torch.cuda.empty_cache()
+    steps = max(10, args.steps)
+    for _ in range(3):
+        M.sr.smvm_into(yh, A, xh)
+    ts = per_step_ms(torch, lambda: M.sr.smvm_into(yh, A, xh), steps)
+    ms, med = sum(ts) / len(ts), median(ts)
+    byt = nnz * (4 + 4) + n * 8 + n * 4 + n * 4     # entries (f32 value + i32 column) + row offsets + y + x
+    out = {"workload": "COO->CSR assembly + SpMV, RMAT scale %d, edge factor 18, f32 (BASELINE configs[2])" % args.c3_scale,
+           "nnz0": nnz0, "nnz": nnz, "assembly_ms": round(asm_ms, 3), "assembly_Mtriples_per_s": round(nnz0 / asm_ms / 1e3, 1),
+           "assembly_frac_of_peak_on_compulsory_bytes": round((nnz0 * 20 + nnz * 8 + n * 8) / asm_ms / 1e6 / HBM_PEAK_GBS, 4),
+           "steps": steps, "ms_per_step": round(ms, 4), "ms_per_step_median": round(med, 4),
+           "GFLOPs": round(2.0 * nnz / med / 1e6, 1), "algorithmic_bytes": byt,
+           "achieved_GBs": round(byt / med / 1e6, 1), "frac": round(byt / med / 1e6 / HBM_PEAK_GBS, 4),
+           "frac_of_mean": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4),
+           "spmv_path": SPMV_PATHS.get(path, str(path)), "pb_fold": ctx.get_option("spmv_last_pb_fold"),
+           "first_product_ms_nothing_built": round(first_ms, 3), "first_product_path": SPMV_PATHS.get(first_path, str(first_path)),
+           "prepare_ms": round(prep_ms, 2),
+           "parity": "y within 1e-5 of torch's f64 scatter-add of the generated triples (max rel %.2g)" % rel}
+    del A, xh, yh, x, y
+    ctx.clear_caches()
+    torch.cuda.empty_cache()
+    return out
+
+
+def c4_leg(args, torch, dev, ctx):
+    """BASELINE configs[3]: banded n = 2^20, 27 entries per row, times a dense 64-column f64 panel."""
+    from sparse_amd import mk_compressed, synth
+    n, k = 1 << 20, 64
+    M = mk_compressed("f64", ctx)
+    r, c, v = synth.banded_coo_device(n, 13, dev)
+    nnz0 = r.numel()
+    A = M.sr.sparse(n, n, (r, c, v))
+    del A
+    ctx.sync()
+    t0 = time.perf_counter()
+    A = M.sr.sparse(n, n, (r, c, v))
+    ctx.sync()
+    asm_ms = (time.perf_counter() - t0) * 1e3
+    del r, c, v
+    nnz = A.stored_dims()[2]
+    B = torch.rand(n, k, device=dev, dtype=torch.float64) + 0.5
+    Bh = ctx.array(B, "f64", 2)
+    C = torch.as_tensor(M.sr.smm(A, Bh), device=dev).clone()
+    # parity gate: the build-defined oracle C[:, j] = smvm A B[:, j] on three columns
+    rel = 0.0
+    for j in (0, 31, 63):
+        yj = torch.as_tensor(M.sr.smvm(A, B[:, j].contiguous()), device=dev)
+        rel = max(rel, float(((C[:, j] - yj).abs() / yj.abs().clamp_min(1e-300)).max()))
+    assert rel <= 1e-12, "C4 leg: SpMM column differs from smvm on that column by %g" % rel
+    del C
+    steps = max(10, args.steps)
+    for _ in range(3):
+        M.sr.smm(A, Bh)
+    ts = per_step_ms(torch, lambda: M.sr.smm(A, Bh), steps)
+    ms, med = sum(ts) / len(ts), median(ts)
+    byt = nnz * (8 + 4) + n * 8 + (n + n) * k * 8
+    # the ceiling of this kernel's own mix: per 1024-entry tile 12 KB of entries + the tile's share of B in, of C out
+    tiles = (nnz + 1023) // 1024
+    rd = (12288 + n * k * 8 // tiles) // 16 * 16
+    wr = (n * k * 8 // tiles) // 16 * 16
+    gbs, us = ctx.measure_bandwidth(rd, wr, tiles)
+    out = {"workload": "SpMM: banded n = 2^20, half bandwidth 13 (27 per row), f64, times a dense [n][64] panel (BASELINE configs[3])",
+           "nnz": nnz, "k": k, "assembly_ms": round(asm_ms, 3), "assembly_Mtriples_per_s": round(nnz0 / asm_ms / 1e3, 1),
+           "steps": steps, "ms_per_step": round(ms, 4), "ms_per_step_median": round(med, 4),
+           "TFLOPs": round(2.0 * nnz * k / med / 1e9, 2), "algorithmic_bytes": byt, "achieved_GBs": round(byt / med / 1e6, 1),
+           "frac": round(byt / med / 1e6 / HBM_PEAK_GBS, 4),
+           "mix_ceiling": {"us": round(us, 1), "GBs": round(gbs, 1), "read_bytes_per_tile": rd, "write_bytes_per_tile": wr, "tiles": tiles,
+                           "note": "the same bytes per tile streamed in and out with no arithmetic (measure_bandwidth)"},
+           "frac_of_mix_ceiling": round(us / 1e3 / med, 4),
+           "parity": "columns 0, 31, 63 of C within 1e-12 of smvm on those columns of B (max rel %.2g)" % rel}
+    del A, B, Bh
+    ctx.clear_caches()
+    torch.cuda.empty_cache()
+    return out
+
+
+SPMV_PATHS = {0: "stream", 1: "hot-column renumbering", 2: "column blocks", 3: "two passes"}
+
+
 def max_over_ranks(torch, dist, dev, v):
     if dist is None:
         return v
@@ -126,6 +282,10 @@ def c5_leg(args, torch, dist, world, rank, dev, ctx, M):
     asm_s = max_over_ranks(torch, dist, dev, time.perf_counter() - t0)
     rlo, rhi = D.bounds[rank], D.bounds[rank + 1]
     D.x_own.copy_(1.0 + (torch.arange(rlo, rhi, device=dev) % 7).double())          # integer-valued x
+    t0 = time.perf_counter()
+    D.prepare(1 << 20)                        # many products follow: this rank's record builds its two-pass copy now
+    ctx.sync()
+    prep_s = max_over_ranks(torch, dist, dev, time.perf_counter() - t0)
     # ---- parity gate: torch's own scatter-add of the generated triples (global, summed over the ranks)
     y = D.smvm().clone()
     path = ctx.get_option("spmv_last_path")
@@ -165,7 +325,11 @@ def c5_leg(args, torch, dist, world, rank, dev, ctx, M):
             "x_exchange": D.mode, "x_exchange_impl": getattr(D.plan, "allgather_impl", None),
             "x_exchange_tuning_ms": {k: round(v * 1e3, 4) for k, v in tuned.items()},
             "x_exchange_ms_alone": round(ex_ms, 4), "kernel_ms_alone": round(kern_ms, 4),
-            "spmv_path": {0: "stream", 1: "hot-column renumbering", 2: "column blocks", 3: "two passes"}.get(path, str(path)),
+            "spmv_path": SPMV_PATHS.get(path, str(path)),
+            "prepare_ms": round(prep_s * 1e3, 2),
+            "collectives": {"backend": (dist.get_backend() if dist is not None else None), "ranks_seen": world,
+                            "rccl_version": (".".join(str(p) for p in torch.cuda.nccl.version()) if dist is not None and args.backend == "nccl" else None),
+                            "NCCL_DEBUG": os.environ.get("NCCL_DEBUG")},
             "rows_this_rank": rhi - rlo, "parity": "y == scatter-add of the generated triples (integer-valued data), bit for bit"}
 
 
@@ -176,6 +340,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the 1e9-triple strong-scaling leg")
+    ap.add_argument("--no-legs", action="store_true", help="skip the c3 (RMAT SpMV) and c4 (SpMM) legs")
+    ap.add_argument("--c3-scale", type=int, default=24, help="RMAT scale of the c3 leg (rehearsal: smaller)")
     ap.add_argument("--algo", type=int, default=0)
     # rehearsal switches (defaults are the measured configuration)
     ap.add_argument("--grid", type=int, default=GRID, help="grid edge per GPU (default 4096 = BASELINE configs[1])")
@@ -233,6 +399,7 @@ def main():
         nnz0 = r.numel()
         del r, c, v
         D = None
+        M.sr.prepare(A, 1 << 20)      # a loop of products follows: the 16-bit index arrays are built here, not at the 16th step
         x = synth.laplacian_x_device(0, n_loc, dev)
         y = torch.empty(n_loc, dtype=torch.float64, device=dev)
         xh, yh = ctx.array(x, "f64"), ctx.array(y, "f64")       # handles made once: a step is one C call
@@ -247,6 +414,7 @@ def main():
         asm_s = time.perf_counter() - t_asm0
         del r, c, v
         A = D.A
+        D.prepare(1 << 20)
         D.x_own.copy_(synth.laplacian_x_device(rank * n_loc, (rank + 1) * n_loc, dev))
         x = D.x_own
     torch.cuda.empty_cache()
@@ -266,19 +434,22 @@ def main():
         want = synth.laplacian_2d_apply_rows(g, g * world, rank * n_loc, (rank + 1) * n_loc, dev)
     assert torch.equal(got, want), "SpMV result differs from the stencil applied directly"
     del want
+    # ---- the contract: W warm-up steps, then exactly K timed steps.  Nothing else runs in between.
+    for _ in range(args.warmup):
+        step()
+    el, dev_ms = timed_steps(torch, dist, step, args.steps)
+    # ---- per-step device times of K more steps (median)
+    step_ms = per_step_ms(torch, step, args.steps)
     # ---- reproducibility gate: the product is claimed bit-reproducible (no atomics on this path); SETTLE further
-    # products must give the same bits.  Untimed, before the W warm-up steps, and reported as "settle_steps": on a
-    # fresh card it is also what brings the clocks to their steady state (a 5 + 20 step run straight after the
-    # assembly measured 0.206 ms per step where 200 steps measure 0.194).
+    # products must give the same bits.  It runs AFTER the timed region (round 2 had it in front, where it also
+    # warmed the card: 0.206 -> 0.194 ms per step); what a card that has been busy that long delivers is
+    # reported separately as `settled`.
     ref_y = got.clone()
     for _ in range(SETTLE):
         step()
     assert torch.equal(step(), ref_y), "SpMV is not reproducible bit for bit"
     del ref_y
-
-    for _ in range(args.warmup):
-        step()
-    el, dev_ms = timed_steps(torch, dist, step, args.steps)
+    el_settled, dev_ms_settled = timed_steps(torch, dist, step, args.steps)
 
     # kernel-only timing (no exchange) for the roofline entry
     if D is not None:
@@ -293,6 +464,8 @@ def main():
         ib = ctx.get_option("spmv_last_col_bytes")
         m_loc = n_loc
         ex_ms = 0.0
+    el_settled = max_over_ranks(torch, dist, dev, el_settled)
+    D_none = D is None
 
     el = max_over_ranks(torch, dist, dev, el)
     if dist is not None:
@@ -304,15 +477,27 @@ def main():
 
     # ---- second leg: the 1e9-triple matrix north_star scales on (all ranks take part)
     lap_mode = "none" if D is None else D.mode
-    c5 = None
+    # the card's own ceilings for this kernel's access mix (one 1024-entry tile per workgroup: entries, row offsets and
+    # the tile's share of x in; its share of y out), measured now, in this process
+    nnz_loc = A.stored_dims()[2] if D is None else D.A.stored_dims()[2]
+    ntl_loc = max(1, (nnz_loc + 1023) // 1024)
+    ceil = None
+    if rank == 0:
+        rd_g = (1024 * (8 + ib) + (n_loc * 2 + m_loc * 8) // ntl_loc) // 16 * 16
+        wr_g = max(16, (n_loc * 8 // ntl_loc) // 16 * 16)
+        ceil = measured_ceilings(ctx, rd_g, wr_g, ntl_loc)
+    c5 = c3 = c4 = None
+    del A, D, got, x
+    if world == 1:
+        del xh, yh, y
+    else:
+        del xf
+    ctx.clear_caches()
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_legs:
+        c3 = c3_leg(args, torch, dev, ctx)
+        c4 = c4_leg(args, torch, dev, ctx)
     if not args.no_c5:
-        del A, D, got, x
-        if world == 1:
-            del xh, yh, y
-        else:
-            del xf
-        ctx.clear_caches()
-        torch.cuda.empty_cache()
         c5 = c5_leg(args, torch, dist, world, rank, dev, ctx, M)
 
     if rank == 0:
@@ -329,10 +514,15 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and g == GRID:   # the PMC pass was taken on the 4096^2 per-GPU workload
             try:
-                traffic = json.load(open(tpath)).get("spmv_c2_f64_hbm_bytes_per_launch")
-                traffic_src = "stored: profiles/pmc_traffic.json (rocprofv3 --pmc passes of bench/pmc_traffic.sh), not measured in this run"
+                tj = json.load(open(tpath))
+                traffic = tj.get("spmv_c2_f64_hbm_bytes_per_launch")
+                traffic_src = ("stored: profiles/pmc_traffic.json (rocprofv3 --pmc passes of bench/pmc_traffic.sh on tree %s, kernel %s), "
+                               "not measured in this run" % (tj.get("git_sha", "of round 2 (sha not recorded)"), tj.get("kernel", "?")))
             except Exception:
                 traffic = None
+        med_ms = median(step_ms)
+        ms_settled = el_settled / args.steps * 1e3
+        mix = ceil["kernel_mix"]["GBs"] if ceil else None
         out = {
             "metric": "CSR f64 SpMV GFLOP/s + achieved HBM GB/s (% peak) at 1/2/4/8 MI355X",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
@@ -343,12 +533,25 @@ def main():
                        "x_exchange": lap_mode,
                        "x_exchange_ms_alone": round(ex_ms, 5),
                        "assembly_s": round(asm_s, 4), "assembly_Mtriples_per_s": round(nnz0 / asm_s / 1e6, 1),
-                       "settle_steps": SETTLE,
-                       "settle_note": "untimed products of the bit-reproducibility gate, run before the warm-up steps"},
+                       "products_before_timed_region": 1 + args.warmup,
+                       "order": "parity gate (1 product), --warmup steps, the timed steps; the reproducibility gate runs afterwards"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_ms": round(kern_ms, 5), "algorithmic_bytes": alg_bytes},
+                         "kernel_ms": round(kern_ms, 5), "algorithmic_bytes": alg_bytes,
+                         "kernel_ms_median": round(med_ms, 5) if D_none else None,
+                         "frac_median": round(alg_bytes / (med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if D_none else None,
+                         "peak_measured": ceil,
+                         "frac_of_measured": round(achieved / mix, 4) if mix else None,
+                         "frac_of_measured_note": "achieved / the GB/s the same bytes per tile reach with no arithmetic (peak_measured.kernel_mix)"},
+            "settled": {"ms_per_step": round(ms_settled, 5), "value": round(2.0 * nnz_glob / ms_settled / 1e6, 2),
+                        "frac": round(alg_bytes / (dev_ms_settled * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if D_none else None,
+                        "preceded_by_products": 1 + args.warmup + 2 * args.steps + SETTLE + 1,
+                        "note": "the same K steps timed again after the reproducibility gate: a card that has been busy for ~0.1 s"},
         }
+        if c3 is not None:
+            out["c3"] = c3
+        if c4 is not None:
+            out["c4"] = c4
         if c5 is not None:
             out["c5"] = c5
         if world == 1 and not args.no_cpu_baseline:

@@ -23,7 +23,10 @@ for tag in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
 m = {k: v[0] / v[1] for k, v in acc.items()}
 read_b = 2 * m["FETCH_SIZE"] * 1024          # gfx950: 128-B read requests are tallied at 64 B
 write_b = m["WRITE_SIZE"] * 1024
+sha_path = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), ".build_sha")
+sha = open(sha_path).read().split() if os.path.exists(sha_path) else ["unknown", "0"]
 res = {
+    "git_sha": sha[0] + (" + %s uncommitted files" % sha[1] if len(sha) > 1 and sha[1] != "0" else ""),
     "command": "bench/pmc_traffic.sh: rocprofv3 --pmc <counter> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-c5 (one pass per counter group)",
     "kernel": kname + " on the C2 workload (5-point Laplacian 4096^2, f64)",
     "dispatches_averaged": acc["FETCH_SIZE"][1],

@@ -1,4 +1,8 @@
-// spmv_2d.hpp -- one-pass SpMV for gather-bound power-law records with BOTH slices in LDS
+// spmv_2d_lab.hpp -- LAB MATERIAL, not compiled into the product since round 3 (it was sparse_amd/csrc/spmv_2d.hpp,
+// option spmv_2d, path 4): measured 2.27-2.45 ms on C3 against 0.7 ms for the two-pass product
+// (profiles/r02_2d_blocked_lab_c3.txt) and never chosen by itself.  Kept for the record of what was tried.
+//
+// one-pass SpMV for gather-bound power-law records with BOTH slices in LDS
 // (BASELINE configs[2]; sr.smvm, compressed.fut:134-146).
 //
 // The two-pass product (spmv_pb.hpp) keeps every gather inside the CU but pays for it with a product stream:

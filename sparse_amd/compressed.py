@@ -147,6 +147,14 @@ class Context:
     def get_option(self, key):
         return int(self.L.sparse_amd_context_get_option(self.h, key.encode()))
 
+    def measure_bandwidth(self, read_bytes_per_group, write_bytes_per_group, groups):
+        """(GB/s, microseconds per launch) of a streaming read/write mix with no arithmetic
+        (sparse_amd_context_measure_bandwidth): the measured ceiling a kernel of that access mix can be held against."""
+        gbs, us = ctypes.c_double(), ctypes.c_double()
+        self.check(self.L.sparse_amd_context_measure_bandwidth(self.h, _I64(read_bytes_per_group), _I64(write_bytes_per_group),
+                                                               _I64(groups), ctypes.byref(gbs), ctypes.byref(us)))
+        return gbs.value, us.value
+
     def close(self):
         if self.h:
             self.L.futhark_context_free(self.h)
@@ -321,6 +329,13 @@ class _Module:
         out = _VP()
         self.ctx.check(self._f("sparse")(self.ctx.h, ctypes.byref(out), _I64(n), _I64(m), rs.h, cs.h, vs.h))
         return self._new(out)
+
+    def prepare(self, A, expected_products):
+        """How many products the caller will run with A (sparse_amd_<kind>_<t>_prepare): 16 or more builds the
+        record's faster SpMV form now, fewer pins the form that needs nothing built.  No counterpart in the reference."""
+        f = getattr(self.ctx.L, "sparse_amd_%s_%s_prepare" % (self.kind, self.t))
+        self.ctx.check(f(self.ctx.h, self._chk(A), _I64(int(expected_products))))
+        return A
 
     def nnz(self, A):
         out = _I64()

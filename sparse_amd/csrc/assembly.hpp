@@ -124,7 +124,12 @@ __device__ __forceinline__ void tile_rows(const int64_t *__restrict__ row_ptr, c
 #pragma unroll
   for (int k = 0; k < 4; k++) mark[k * kBlock + tid] = 0u;
   __syncthreads();
-  for (int64_t r = lb0 + tid; r < lb1; r += kBlock) atomicMax(&mark[(int)(row_ptr[r] - base)], (unsigned)(r - rfirst));
+  // The last tile lists the record's trailing empty rows too (tile_lb[ntiles] = n): their start is nnz, which is one
+  // past the tile when nnz is a multiple of the tile size.  No entry reads that mark, so such rows leave none.
+  for (int64_t r = lb0 + tid; r < lb1; r += kBlock) {
+    const int64_t off = row_ptr[r] - base;
+    if (off < 4 * kBlock) atomicMax(&mark[(int)off], (unsigned)(r - rfirst));
+  }
   __syncthreads();
   unsigned v[4];
 #pragma unroll
@@ -315,6 +320,78 @@ template <> struct BitsOf<double> { typedef uint64_t type; };
 template <> struct BitsOf<float> { typedef uint32_t type; };
 template <> struct BitsOf<int32_t> { typedef uint32_t type; };
 
+// ---------------------------------------------------------------- long runs of one coordinate
+// A run of equal keys is folded by the thread that holds its first pair, one add after the other, in input order:
+// the reference's order after a stable sort (compressed.fut:76-87), and what lets the parity tests hold merged
+// floating-point values bit for bit.  That is a dependent loop as long as the run, so it is bounded: a run of more
+// than kLongRun pairs (found with ONE load -- the keys are sorted, so keys[i + kLongRun] == keys[i] says it all) is
+// put on a list instead and summed afterwards by a whole workgroup (fold_long_runs_kernel): every thread adds the
+// pairs i + t, i + t + 256, ... in that order into four interleaved partial sums, the partial sums are combined in
+// a fixed tree.  Deterministic (run to run, bit for bit); exact for i32 (wrapping adds commute); for floats it is a
+// different order than left to right -- compressed.fut:83-84 is a segmented_reduce, whose order the language leaves
+// open -- and at least as accurate (partial sums of n / 1024 terms instead of one of n).
+constexpr int64_t kLongRun = 4096;
+
+template <class K, class T>
+__global__ __launch_bounds__(kBlock) void fold_long_runs_kernel(const K *__restrict__ keys, const uint32_t *__restrict__ perm,
+                                                                const T *__restrict__ vals_in, int64_t count,
+                                                                const unsigned long long *__restrict__ long_list,
+                                                                T *__restrict__ vals_out) {
+  __shared__ T part[kWaves];
+  const int tid = threadIdx.x;
+  const unsigned long long nlist = long_list[0];
+  for (unsigned long long b = blockIdx.x; b < nlist; b += gridDim.x) {  // uniform over the block
+    const int64_t start = (int64_t)long_list[1 + 2 * b], slot = (int64_t)long_list[2 + 2 * b];
+    const K k = keys[start];
+    // end of the run: gallop, then bisect (every thread the same loads)
+    int64_t lo = start + kLongRun, step = kLongRun;  // keys[lo] == k is known
+    while (lo + step < count && keys[lo + step] == k) { lo += step; step *= 2; }
+    int64_t hi = lo + step < count ? lo + step : count;  // keys[hi] != k or hi == count
+    while (hi - lo > 1) {
+      const int64_t mid = lo + (hi - lo) / 2;
+      if (keys[mid] == k) lo = mid; else hi = mid;
+    }
+    const int64_t end = hi;
+    T acc[4] = {(T)0, (T)0, (T)0, (T)0};
+    int64_t q = start + tid;
+    for (; q + 3 * kBlock < end; q += 4 * kBlock) {
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = vals_in[perm ? (int64_t)perm[q + u * kBlock] : q + u * kBlock];
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[u] = (T)(acc[u] + v[u]);
+    }
+    for (int u = 0; q < end; q += kBlock, u++) acc[u] = (T)(acc[u] + vals_in[perm ? (int64_t)perm[q] : q]);
+    T sum = (T)((T)(acc[0] + acc[1]) + (T)(acc[2] + acc[3]));
+    sum = wave_reduce(sum, OpAdd());
+    __syncthreads();  // part[] of the previous run has been read
+    if ((tid & 63) == 0) part[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      T total = part[0];
+#pragma unroll
+      for (int w = 1; w < kWaves; w++) total = (T)(total + part[w]);
+      vals_out[slot] = total;
+    }
+  }
+}
+
+// Queues fold_long_runs_kernel for a list filled by an emission kernel; n_known >= 0: the list's length is already on
+// the host (nothing is launched for an empty one), < 0: the kernel reads it from the list itself.
+template <class K, class T>
+int fold_long_runs(futhark_context *ctx, const K *keys, const uint32_t *perm, const T *vals_in, int64_t count,
+                   const unsigned long long *long_list, int64_t n_known, T *vals_out) {
+  if (n_known == 0) return 0;
+  int64_t grid = n_known > 0 ? n_known : count / kLongRun;
+  const int64_t cap = (int64_t)ctx->num_cu * 4;
+  if (grid > cap) grid = cap;
+  if (grid < 1) return 0;
+  hipLaunchKernelGGL((fold_long_runs_kernel<K, T>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, keys, perm, vals_in,
+                     count, long_list, vals_out);
+  SAMD_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
 // INDIRECT: vals_in is in source order and perm[i] is the source of sorted entry i
 // (nullptr = identity); otherwise vals_in is already in key order.
 template <class K, class T, class I, bool INDIRECT>
@@ -323,7 +400,8 @@ __global__ __launch_bounds__(kBlock) void merge_emit_kernel(const K *__restrict_
                                                             const uint32_t *__restrict__ slot,  // inclusive head count
                                                             const T *__restrict__ vals_in, int64_t count,
                                                             int minor_bits, K minor_mask, I *__restrict__ col_out,
-                                                            T *__restrict__ vals_out, int64_t *__restrict__ row_ptr) {
+                                                            T *__restrict__ vals_out, int64_t *__restrict__ row_ptr,
+                                                            unsigned long long *__restrict__ long_list) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= count) return;
   const K k = keys[i];
@@ -335,7 +413,13 @@ __global__ __launch_bounds__(kBlock) void merge_emit_kernel(const K *__restrict_
     auto src = [&](int64_t q) -> int64_t { return (INDIRECT && perm) ? (int64_t)perm[q] : q; };
     T acc = vals_in[src(i)];
     if (has_next && knext == k) {
-      for (int64_t j = i + 1; j < count && keys[j] == k; j++) acc = (T)(acc + vals_in[src(j)]);
+      if (long_list && i + kLongRun < count && keys[i + kLongRun] == k) {  // sorted keys: the run is longer than kLongRun
+        const unsigned long long slot = atomicAdd(long_list, 1ull);
+        long_list[1 + 2 * slot] = (unsigned long long)i;
+        long_list[2 + 2 * slot] = (unsigned long long)(s - 1);
+      } else {
+        for (int64_t j = i + 1; j < count && keys[j] == k; j++) acc = (T)(acc + vals_in[src(j)]);
+      }
     }
     col_out[s - 1] = (I)(k & minor_mask);
     vals_out[s - 1] = acc;
@@ -363,7 +447,8 @@ __global__ __launch_bounds__(kBlock) void fold_emit_kernel(const K *__restrict__
                                                            unsigned long long *__restrict__ status,
                                                            uint32_t *__restrict__ ticket,
                                                            unsigned long long *__restrict__ merged_out,
-                                                           int *__restrict__ err, int lab) {
+                                                           int *__restrict__ err, int lab,
+                                                           unsigned long long *__restrict__ long_list) {
   __shared__ uint32_t sh[kWaves];
   __shared__ uint32_t s_tile;
   __shared__ unsigned long long s_off;
@@ -380,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void fold_emit_kernel(const K *__restrict__
   K k[kFoldItems], kn[kFoldItems];
   T val[kFoldItems];
   uint32_t v[kFoldItems];
-  uint32_t headmask = 0;
+  uint32_t headmask = 0, longmask = 0;  // longmask: heads whose run goes to fold_long_runs_kernel
 #pragma unroll
   for (int j = 0; j < kFoldItems; j++) {
     const uint32_t i = base + j * 64;
@@ -420,6 +505,10 @@ __global__ __launch_bounds__(kBlock) void fold_emit_kernel(const K *__restrict__
       q = i + 2;
       if (q >= count || knext2 != k[j]) continue;
     }
+    if ((uint64_t)i + kLongRun < (uint64_t)count && keys[(uint64_t)i + kLongRun] == k[j]) {  // more than kLongRun pairs
+      longmask |= 1u << j;
+      continue;
+    }
     for (; q < count && keys[q] == k[j]; q++) val[j] = (T)(val[j] + vals_in[src(q)]);
   }
   if (tid < 64) {  // wave 0: the tile's first output slot
@@ -445,6 +534,11 @@ __global__ __launch_bounds__(kBlock) void fold_emit_kernel(const K *__restrict__
     if (headmask & (1u << j)) {
       col_out[s - 1] = (I)(k[j] & minor_mask);
       if (!(lab & 4)) vals_out[s - 1] = val[j];
+      if (longmask & (1u << j)) {  // summed afterwards by a workgroup; the value just stored is overwritten
+        const unsigned long long e = atomicAdd(long_list, 1ull);
+        long_list[1 + 2 * e] = (unsigned long long)i;
+        long_list[2 + 2 * e] = s - 1;
+      }
     }
     const K major = shr_safe<K>(k[j], minor_bits);
     if (i + 1 >= count || shr_safe<K>(kn[j], minor_bits) != major) row_ptr[(int64_t)major + 1] = (int64_t)s;
@@ -742,17 +836,21 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
       SAMD_HIP(ctx, hipMemsetAsync(fticket.p, 0, sizeof(uint32_t), ctx->stream));
       SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t) * 2, ctx->stream));
       unsigned long long *merged_dev = reinterpret_cast<unsigned long long *>(ctx->d_small);
+      Tmp<unsigned long long> longl(ctx);  // [0] = runs listed, then (first pair, output slot) of each
+      SAMD_TRY(longl.get(1 + 2 * (count / kLongRun + 1)));
+      SAMD_HIP(ctx, hipMemsetAsync(longl.p, 0, sizeof(unsigned long long), ctx->stream));
       if (c32)
         hipLaunchKernelGGL((fold_emit_kernel<K, T, int32_t, true>), dim3((unsigned)ftiles), dim3(kBlock), 0, ctx->stream,
                            (const K *)ks, perm, vs, (uint32_t)count, minor_bits, minor_mask_f, b->col32, b->vals, b->row_ptr,
-                           fstatus.p, fticket.p, merged_dev, sort_err, (int)((ctx->opt_ablate >> 20) & 7));
+                           fstatus.p, fticket.p, merged_dev, sort_err, (int)((ctx->opt_ablate >> 20) & 7), longl.p);
       else
         hipLaunchKernelGGL((fold_emit_kernel<K, T, int64_t, true>), dim3((unsigned)ftiles), dim3(kBlock), 0, ctx->stream,
                            (const K *)ks, perm, vs, (uint32_t)count, minor_bits, minor_mask_f, b->col64, b->vals, b->row_ptr,
-                           fstatus.p, fticket.p, merged_dev, sort_err, (int)((ctx->opt_ablate >> 20) & 7));
+                           fstatus.p, fticket.p, merged_dev, sort_err, (int)((ctx->opt_ablate >> 20) & 7), longl.p);
       SAMD_LAUNCH_CHECK(ctx);
       if (err_flag)
         SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 1, err_flag, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+      SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 3, longl.p, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
       int64_t host[4];
       SAMD_TRY(read_small(ctx, ctx->d_small, 4, host));
       if (ctx->opt_sort_inject && allow_retry) host[2] = 1;
@@ -765,6 +863,8 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
         return set_error(ctx, "Error: index out of bounds in sparse (assertion 0 <= r < n && 0 <= c < m failed)");
       merged = host[0];
       b->nnz = merged;
+      ctx->last_long_runs = host[3];
+      SAMD_TRY((fold_long_runs<K, T>(ctx, ks, perm, vs, count, longl.p, host[3], b->vals)));  // before vals may be cut down
       if (merged * 4 < count * 3) {  // many duplicates: do not keep count-sized arrays for the record's lifetime
         T *v2 = nullptr;
         SAMD_TRY(dalloc(ctx, &v2, merged));
@@ -816,18 +916,25 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     SAMD_TRY(dalloc(ctx, &b->vals, merged));
     const K minor_mask = minor_bits >= (int)(sizeof(K) * 8) ? (K)~(K)0 : (K)(((K)1 << minor_bits) - 1);
     const unsigned grid = (unsigned)cdiv(count, kBlock);
+    Tmp<unsigned long long> longl(ctx);
+    const bool may_be_long = count > kLongRun;
+    if (may_be_long) {
+      SAMD_TRY(longl.get(1 + 2 * (count / kLongRun + 1)));
+      SAMD_HIP(ctx, hipMemsetAsync(longl.p, 0, sizeof(unsigned long long), ctx->stream));
+    }
     if (use_col32(ctx, n_minor)) {
       SAMD_TRY(dalloc(ctx, &b->col32, merged));
       hipLaunchKernelGGL((merge_emit_kernel<K, T, int32_t, true>), dim3(grid), dim3(kBlock), 0, ctx->stream,
                          (const K *)ks, perm, (const uint32_t *)slots, vs, count, minor_bits, minor_mask, b->col32,
-                         b->vals, b->row_ptr);
+                         b->vals, b->row_ptr, longl.p);
     } else {
       SAMD_TRY(dalloc(ctx, &b->col64, merged));
       hipLaunchKernelGGL((merge_emit_kernel<K, T, int64_t, true>), dim3(grid), dim3(kBlock), 0, ctx->stream,
                          (const K *)ks, perm, (const uint32_t *)slots, vs, count, minor_bits, minor_mask, b->col64,
-                         b->vals, b->row_ptr);
+                         b->vals, b->row_ptr, longl.p);
     }
     SAMD_LAUNCH_CHECK(ctx);
+    if (may_be_long) SAMD_TRY((fold_long_runs<K, T>(ctx, ks, perm, vs, count, longl.p, -1, b->vals)));
     if (n_major > 0)
       SAMD_TRY((device_scan<int64_t, OpMax, PtrIn<int64_t>, false>(ctx, PtrIn<int64_t>{b->row_ptr + 1}, n_major,
                                                                     (int64_t)0, OpMax(), b->row_ptr + 1,
@@ -843,6 +950,19 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
   *out = guard.release();
   return 0;
 }
+
+// What the pack step leaves in the context for the sort that follows (digit histograms, early samples, the
+// scan-passes-only switch) is cleared on EVERY way out of the functions that set it, error returns included: a stale
+// sample would otherwise steer a later assembly of the same size and key width.
+struct PreStateGuard {
+  futhark_context *ctx;
+  explicit PreStateGuard(futhark_context *c) : ctx(c) {}
+  ~PreStateGuard() {
+    ctx->pre_hist = nullptr;
+    ctx->pre_sample = false;
+    ctx->sort_force_scan = false;
+  }
+};
 
 // sr.sparse n_major n_minor (zip3 major minor vals)
 template <class T>
@@ -867,6 +987,7 @@ int assemble_coo(futhark_context *ctx, int64_t n_major, int64_t n_minor, const i
   }
   Tmp<uint64_t> keys(ctx);
   Tmp<uint32_t> hist3(ctx);
+  PreStateGuard pre_guard(ctx);
   SAMD_TRY(keys.get(count));
   for (int attempt = 0; attempt < 2; attempt++) {
     // large inputs whose sort may go the top-bits-first way (first attempt only): digit counts taken while packing
@@ -979,6 +1100,7 @@ int transpose_physical(futhark_context *ctx, const CsrBody<T> *a, CsrBody<T> **o
   }
   Tmp<uint64_t> keys(ctx);
   Tmp<uint32_t> hist(ctx);
+  PreStateGuard pre_guard(ctx);
   SAMD_TRY(keys.get(a->nnz));
   const int passes = (cbits + 7) / 8;
   if (a->nnz >= kMsdMinCount && a->nnz < 0xffffffffLL && a->tile == 4 * kBlock && a->n < 0x7fffffffLL && ctx->opt_sort_algo == 0 &&

@@ -8,11 +8,12 @@
 #include "assembly.hpp"
 #include "spmv.hpp"
 #include "spmv_pb.hpp"
-#include "spmv_2d.hpp"
 #include "spmm.hpp"
 #include "convert.hpp"
 #include "mono.hpp"
 #include "mtx.hpp"
+#include "store_format.hpp"
+#include "bwprobe.hpp"
 
 using namespace samd;
 
@@ -344,15 +345,7 @@ int e_from_fields(futhark_context *ctx, H **out, int64_t n, int64_t m, const fut
 }
 
 // ---- store / restore of the opaque sr / sc values (the serialisers `futhark c --library` generates for
-// every opaque type; the byte format is the library's own).  Layout: "SAMDCSR1", 8-byte element tag,
-// int64 n, m, nnz of the STORED record (for a csc handle: of the transpose, compressed.fut:226), then
-// row_off[n] i64 (inclusive, :94), col_idx[nnz] i64, vals[nnz].
-struct StoreHeader {
-  char magic[8];
-  char tag[8];
-  int64_t n, m, nnz;
-};
-
+// every opaque type; the byte format is the library's own: store_format.hpp).
 template <class T> struct TagOf;
 template <> struct TagOf<double> { static const char *name() { return "f64"; } };
 template <> struct TagOf<float> { static const char *name() { return "f32"; } };
@@ -403,16 +396,12 @@ int e_store(futhark_context *ctx, const H *a, void **p, size_t *n) {
 
 template <class T, class H>
 H *e_restore(futhark_context *ctx, const void *p) {
-  if (!p) { set_error(ctx, "restore: null buffer"); return nullptr; }
   StoreHeader h;
-  memcpy(&h, p, sizeof h);
-  if (memcmp(h.magic, "SAMDCSR1", 8) != 0) { set_error(ctx, "restore: not a stored sparse_amd matrix"); return nullptr; }
-  h.tag[sizeof h.tag - 1] = 0;
-  if (strcmp(h.tag, TagOf<T>::name()) != 0) {
-    set_error(ctx, "restore: stored element type is %s, wanted %s", h.tag, TagOf<T>::name());
+  char msg[160];
+  if (store_parse_header(p, (size_t)-1, TagOf<T>::name(), sizeof(T), &h, msg, sizeof msg) != 0) {
+    set_error(ctx, "%s", msg);
     return nullptr;
   }
-  if (h.n < 0 || h.m < 0 || h.nnz < 0) { set_error(ctx, "restore: negative size in header"); return nullptr; }
   Tmp<int64_t> ro(ctx), ci(ctx);
   Tmp<T> va(ctx);
   if (ro.get(h.n) != 0 || ci.get(h.nnz) != 0 || va.get(h.nnz) != 0) return nullptr;
@@ -700,6 +689,7 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "sort_msd_chunk")) ctx->opt_sort_msd_chunk = value;
   else if (!strcmp(key, "spmv_reorder")) ctx->opt_spmv_reorder = value;
   else if (!strcmp(key, "spmv_col16")) ctx->opt_spmv_col16 = value;
+  else if (!strcmp(key, "spmv_eager")) ctx->opt_spmv_eager = value;
   else if (!strcmp(key, "spmv_pb")) ctx->opt_spmv_pb = value;
   else if (!strcmp(key, "spmv_pb_rows")) ctx->opt_spmv_pb_rows = value;
   else if (!strcmp(key, "spmv_pb_lines")) ctx->opt_spmv_pb_lines = value;
@@ -708,11 +698,6 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_pb_oround")) ctx->opt_spmv_pb_oround = value;
   else if (!strcmp(key, "spmv_pb_shares")) ctx->opt_spmv_pb_shares = value;
   else if (!strcmp(key, "spmv_pb_deal")) ctx->opt_spmv_pb_deal = value;
-  else if (!strcmp(key, "spmv_2d")) ctx->opt_spmv_2d = value;
-  else if (!strcmp(key, "spmv_2d_rows")) ctx->opt_spmv_2d_rows = value;
-  else if (!strcmp(key, "spmv_2d_cols")) ctx->opt_spmv_2d_cols = value;
-  else if (!strcmp(key, "spmv_2d_entries")) ctx->opt_spmv_2d_entries = value;
-  else if (!strcmp(key, "spmv_2d_dense")) ctx->opt_spmv_2d_dense = value;
   else if (!strcmp(key, "ablate")) ctx->opt_ablate = value;
   else if (!strcmp(key, "noalloc_scratch_bytes")) ctx->opt_noalloc_scratch_bytes = value;
   else return set_error(ctx, "unknown option '%s'", key);
@@ -728,12 +713,13 @@ int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *k
   if (!strcmp(key, "sort_algo")) return ctx->opt_sort_algo;
   if (!strcmp(key, "sort_msd")) return ctx->opt_sort_msd;
   if (!strcmp(key, "sort_last_msd")) return ctx->last_sort_msd;
+  if (!strcmp(key, "sort_last_long_runs")) return ctx->last_long_runs;
   if (!strcmp(key, "spmv_reorder")) return ctx->opt_spmv_reorder;
+  if (!strcmp(key, "spmv_eager")) return ctx->opt_spmv_eager;
   if (!strcmp(key, "spmv_pb")) return ctx->opt_spmv_pb;
   if (!strcmp(key, "spmv_pb_fold")) return ctx->opt_spmv_pb_fold;
   if (!strcmp(key, "spmv_last_pb_fold")) return ctx->last_pb_fold;
   if (!strcmp(key, "spmv_last_pb_outputs")) return ctx->last_pb_outputs;
-  if (!strcmp(key, "spmv_2d")) return ctx->opt_spmv_2d;
   if (!strcmp(key, "num_cu")) return ctx->num_cu;
   if (!strcmp(key, "spmv_last_path")) return ctx->last_spmv_path;
   if (!strcmp(key, "spmv_last_col_bytes")) return ctx->last_spmv_col_bytes;
@@ -741,6 +727,12 @@ int64_t sparse_amd_context_get_option(struct futhark_context *ctx, const char *k
   return -1;
 }
 const char *sparse_amd_version(void) { return "sparse_amd 0.1 (gfx950)"; }
+
+int sparse_amd_context_measure_bandwidth(struct futhark_context *ctx, int64_t read_bytes_per_group,
+                                         int64_t write_bytes_per_group, int64_t groups, double *gb_per_s, double *us) {
+  ENTER(ctx);
+  return measure_bandwidth(ctx, read_bytes_per_group, write_bytes_per_group, groups, gb_per_s, us);
+}
 
 // ------------------------------------------------------------------- arrays
 #define SAMD_ARRAY_1D(NAME, CT)                                                                              \
@@ -996,6 +988,14 @@ SAMD_ARRAY_2D(f64, double)
   int sparse_amd_csr_##TT##_smvm_into_noalloc(CTX, A1(TT) * y, const CSR(TT) * a, const A1(TT) * x) {         \
     ENTER(ctx);                                                                                             \
     return e_smvm_into_noalloc<CT>(ctx, y, a, x);                                                             \
+  }                                                                                                           \
+  int sparse_amd_csr_##TT##_prepare(CTX, const CSR(TT) * a, const int64_t expected_products) {                \
+    ENTER(ctx);                                                                                             \
+    return spmv_prepare<CT>(ctx, a->b, expected_products);                                                    \
+  }                                                                                                           \
+  int sparse_amd_csc_##TT##_prepare(CTX, const CSC(TT) * a, const int64_t expected_products) {                \
+    ENTER(ctx);                                                                                             \
+    return spmv_prepare<CT>(ctx, a->b, expected_products);                                                    \
   }
 
 SAMD_MATRIX(f64, double)
@@ -1426,10 +1426,9 @@ void sparse_amd_mtx_free(void *p) { free(p); }
 
 // --------------------------------------------- one process, several devices (group.hpp)
 int sparse_amd_group_new(struct sparse_amd_group **out, int ndev, const int *devices, const char *transport) {
-  *out = nullptr;
-  if (ndev < 1 || ndev > 64) return 1;
   sparse_amd_group *g = new sparse_amd_group();
   *out = g;  // always returned: the error text lives in it
+  if (ndev < 1 || ndev > 64) return group_error(g, "group: %d members asked for (1..64)", ndev);
   g->G = ndev;
   bool distinct = true;
   for (int k = 0; k < ndev; k++) {
@@ -1462,7 +1461,9 @@ int sparse_amd_group_new(struct sparse_amd_group **out, int ndev, const int *dev
       (void)hipGetLastError();
     }
   }
-  if (ndev > 1 && distinct && !want_peer) {
+  // RCCL: by default for several distinct devices; a group of ONE member opens it only when asked to by name (its
+  // slice of x then travels through a grouped send-to-self, which is how the transport is exercised on a one-GPU box)
+  if (((ndev > 1 && !want_peer) || (ndev == 1 && want_rccl)) && distinct) {
     std::string why;
     if (!g->rccl.load(&why)) {
       if (want_rccl) return group_error(g, "group: %s", why.c_str());
@@ -1484,7 +1485,7 @@ char *sparse_amd_group_get_error(struct sparse_amd_group *g) {
 }
 
 int sparse_amd_group_size(struct sparse_amd_group *g) { return g->G; }
-const char *sparse_amd_group_transport(struct sparse_amd_group *g) { return g->G == 1 ? "none" : (g->use_rccl ? "rccl" : "peer"); }
+const char *sparse_amd_group_transport(struct sparse_amd_group *g) { return g->use_rccl ? "rccl" : (g->G <= 1 ? "none" : "peer"); }
 struct futhark_context *sparse_amd_group_context(struct sparse_amd_group *g, int k) {
   return (k >= 0 && k < g->G) ? g->ctx[(size_t)k] : nullptr;
 }

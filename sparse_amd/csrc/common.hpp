@@ -118,6 +118,7 @@ struct futhark_context {
   int64_t opt_spmm_algo = 0;
   int64_t opt_spmv_cblk = 0;  // 0 auto, > 0 always with this many columns per block, -1 never
   int64_t opt_spmv_reorder = 0;  // 0 auto, 1 always (when the record qualifies by size), -1 never
+  int64_t opt_spmv_eager = 0;  // 1: a record's first product decides and builds everything (the behaviour before round 3; tests)
   int64_t opt_spmv_pb = 0;  // two-pass SpMV (spmv_pb.hpp), 0 large skewed gather-bound records of 4-byte values, 1 also flat popularity, 2 always (tests), -1 never
   int64_t opt_spmv_pb_rows = 0, opt_spmv_pb_lines = 0, opt_spmv_pb_entries = 0;  // test overrides: rows per panel,
                                                                                  // 32-column lines per block, entries per panel
@@ -127,8 +128,6 @@ struct futhark_context {
   int64_t opt_spmv_pb_oround = 0;  // lab: folded layout, alignment of a piece's outputs in products (0 = kPbOutRound)
   int64_t last_pb_fold = 0;      // 1 if the last two-pass product ran on a folded layout; last_pb_outputs: products it wrote (pads included)
   int64_t last_pb_outputs = 0;
-  int64_t opt_spmv_2d = 0;  // 2-D blocked SpMV (spmv_2d.hpp): 0 large skewed records of 4-byte values, 2 always (tests), -1 never
-  int64_t opt_spmv_2d_rows = 0, opt_spmv_2d_cols = 0, opt_spmv_2d_entries = 0, opt_spmv_2d_dense = 0;  // test / lab overrides
   int64_t opt_sort_indirect = 0;  // lab: 1 = assembly sorts 8-byte values by 4-byte source index and gathers them at the end
   int64_t opt_sort_algo = 0;  // 0 one-sweep (look-back), 1 histogram pass + scan per digit
   int64_t opt_fold_emit = 0;       // assembly after an LSD sort: 0 = head flags, scan, fold and emission in one kernel (look-back), -1 = scan + merge_emit
@@ -137,6 +136,7 @@ struct futhark_context {
   bool sort_force_scan = false;    // set while an assembly is repeated after a look-back wait timed out: histogram + scan passes only
   int64_t opt_sort_msd = 0;        // assembly: 0 = top key bits by global passes + the rest in LDS when the sampled buckets are even, -1 never, T > 0 force T top bits
   int64_t opt_sort_msd_chunk = 0;  // lab/tests: nominal chunk length of the in-LDS sort
+  int64_t last_long_runs = 0;      // runs of one coordinate the last assembly handed to fold_long_runs_kernel (tests read it back)
   int64_t last_sort_msd = 0;       // top bits the last assembly's sort gave to the global passes (0 = plain LSD, -1 = tried, did not fit, sorted again)
   int64_t opt_noalloc_scratch_bytes = 0;  // tests: treat the static scratch array as this small (0 = its real size)
   int64_t opt_ablate = 0;  // kernel-lab switch: results are wrong when non-zero
@@ -157,7 +157,7 @@ struct futhark_context {
   int64_t n_entries = 0;
   int64_t last_spmv_col_bytes = 0;  // bytes per column index the last SpMV kernel read (2, 4 or 8)
   int64_t opt_spmv_col16 = 0;  // 16-bit tile-relative columns: 0 decided per record, -1 never
-  int64_t last_spmv_path = 0;  // 0 one-pass, 1 hot-column renumbering, 2 column blocks, 3 two passes, 4 2-D blocks (tests read it back)
+  int64_t last_spmv_path = 0;  // 0 one-pass, 1 hot-column renumbering, 2 column blocks, 3 two passes (tests read it back)
 };
 
 namespace samd {
@@ -269,6 +269,10 @@ struct CsrBody {
   int64_t *tile_lb = nullptr;
   T *head = nullptr;
   int64_t max_row_len = -1;  // filled lazily by the SpMV dispatcher
+  // amortisation (spmv.hpp: spmv_may_build): products multiplied so far, and how many the caller has said it will
+  // run in all (sparse_amd_csr_*_prepare; 0 = not said)
+  mutable int64_t products = 0;
+  mutable int64_t expected_products = 0;
   // 16-bit columns relative to each tile's smallest column (spmv.hpp: col16_prepare), for records whose tiles all
   // span fewer than 65536 columns (banded, stencil); built lazily at the first product of a large record
   mutable int col16_state = 0;  // 0 undecided, 1 active, -1 rejected
@@ -307,10 +311,6 @@ struct CsrBody {
   mutable T *pb_val = nullptr, *pb_prod = nullptr;            // [nnz] values in piece order; products (rewritten per call)
   mutable uint32_t *pb_dgroup = nullptr;                      // [padded entries / 32] pass 1's destination groups
   mutable T *pb_x = nullptr;                                  // [nb * w] x in block order (rewritten per call)
-  // 2-D blocked copy for power-law records (spmv_2d.hpp); built lazily
-  mutable int tb_state = 0;  // 0 undecided, 1 active, -1 rejected
-  mutable void *tb_ext = nullptr;
-  mutable void (*tb_ext_free)(futhark_context *, void *) = nullptr;
   // SpMM: tiles that go to the matrix cores (spmm.hpp), decided at the first product
   mutable int32_t *tile_split = nullptr;  // [ntiles] ids of the dense-block tiles, then of the others
   mutable int64_t n_mfma_tiles = -1;
@@ -349,7 +349,6 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->pb_x);
   dfree(ctx, b->pb_dgroup);
   dfree(ctx, b->pb_wtab);
-  if (b->tb_ext_free) b->tb_ext_free(ctx, b->tb_ext);
   delete b;
 }
 

@@ -139,8 +139,9 @@ int group_smvm(sparse_amd_group *g, sparse_amd_dvec_f64 *y, const sparse_amd_dcs
     if (x->b[(size_t)k] != A->cb[(size_t)k]) return group_error(g, "smvm: x is not partitioned like the matrix's columns");
     if (y->b[(size_t)k] != A->rb[(size_t)k]) return group_error(g, "smvm: y is not partitioned like the matrix's rows");
   }
-  // own slices into place
-  for (int k = 0; k < G; k++) {
+  // own slices into place (a one-member RCCL group sends its slice to itself below instead)
+  const bool self_rccl = G == 1 && g->use_rccl;
+  for (int k = 0; k < G && !self_rccl; k++) {
     futhark_context *c = g->ctx[(size_t)k];
     std::lock_guard<std::mutex> lk(c->mu);
     SAMD_GHIP(g, hipSetDevice(g->dev[(size_t)k]));
@@ -149,12 +150,12 @@ int group_smvm(sparse_amd_group *g, sparse_amd_dvec_f64 *y, const sparse_amd_dcs
       SAMD_GHIP(g, hipMemcpyAsync(A->x_full[(size_t)k] + A->cb[(size_t)k], x->d[(size_t)k], sizeof(double) * (size_t)cnt,
                                   hipMemcpyDeviceToDevice, c->stream));
   }
-  if (G > 1 && g->use_rccl) {
+  if (g->use_rccl) {
     SAMD_GNCCL(g, g->rccl.GroupStart());
     for (int k = 0; k < G; k++) {
       const int64_t mine = A->cb[(size_t)k + 1] - A->cb[(size_t)k];
       for (int j = 0; j < G; j++) {
-        if (j == k) continue;
+        if (j == k && !self_rccl) continue;
         const int64_t theirs = A->cb[(size_t)j + 1] - A->cb[(size_t)j];
         if (mine > 0) SAMD_GNCCL(g, g->rccl.Send(x->d[(size_t)k], (size_t)mine, ncclDouble, j, g->comm[(size_t)k], g->ctx[(size_t)k]->stream));
         if (theirs > 0)

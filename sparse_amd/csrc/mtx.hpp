@@ -48,7 +48,12 @@ inline bool mtx_parse_i64(const char *&p, const char *e, int64_t *out) {
   if (p < e && (*p == '-' || *p == '+')) { neg = *p == '-'; p++; }
   if (p >= e || *p < '0' || *p > '9') return false;
   int64_t v = 0;
-  while (p < e && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); p++; }
+  while (p < e && *p >= '0' && *p <= '9') {
+    const int d = *p - '0';
+    if (v > (INT64_MAX - d) / 10) return false;  // more digits than an i64 holds: malformed, not wrapped
+    v = v * 10 + d;
+    p++;
+  }
   *out = neg ? -v : v;
   return true;
 }

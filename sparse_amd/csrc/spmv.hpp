@@ -449,11 +449,6 @@ template <class T>
 int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat = false);
 template <class T>
 int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y);
-// 2-D blocked path (spmv_2d.hpp)
-template <class T>
-int tb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted);
-template <class T>
-int spmv_2d(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y);
 
 // Decides and, if worthwhile, builds the renumbering.  One-time host synchronisations (two small reads).
 template <class T>
@@ -519,11 +514,6 @@ int reorder_prepare(futhark_context *ctx, const CsrBody<T> *a) {
   }
   // Large, wide, skewed: for 4-byte values the two-pass product with the x and y slices in LDS is faster than any
   // renumbering (C3: 1.25 against 2.08 ms) -- if the record qualifies it takes over and nothing more is built here.
-  // The 2-D blocked product is asked first but only accepts when option spmv_2d > 0 (measured slower: 2.3 ms).
-  if (!force && a->tb_state == 0) {
-    if (tb_prepare<T>(ctx, a, true) != 0) { dfree(ctx, hot_perm); return 1; }
-    if (a->tb_state == 1) { dfree(ctx, hot_perm); return 0; }
-  }
   if (!force && a->pb_state == 0) {
     if (pb_prepare<T>(ctx, a, true) != 0) { dfree(ctx, hot_perm); return 1; }
     if (a->pb_state == 1) { dfree(ctx, hot_perm); return 0; }
@@ -800,12 +790,40 @@ int plan_stats(futhark_context *ctx, const CsrBody<T> *a) {
   return 0;
 }
 
+// 16-bit tile-relative row offsets and the list of rows the fix-up launch folds, for the stream kernel on large
+// records (one-off, one host synchronisation for the list's length)
+template <class T>
+int row_rel_prepare(futhark_context *ctx, const CsrBody<T> *a) {
+  if (a->row_rel) return 0;
+  uint16_t *rel = nullptr;
+  SAMD_TRY(dalloc(ctx, &rel, a->n + 1));
+  hipLaunchKernelGGL(row_rel_kernel, dim3((unsigned)cdiv(a->n + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     (const int64_t *)a->row_ptr, a->n, a->tile, a->ntiles, rel);
+  SAMD_LAUNCH_CHECK(ctx);
+  a->row_rel = rel;
+  if (a->ntiles > 1 && a->ntiles < 0x7fffffffLL) {
+    Tmp<int32_t> fl(ctx);
+    SAMD_TRY(fl.get(4 * a->ntiles));
+    SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
+    hipLaunchKernelGGL((fixup_list_kernel<kSpmvTile>), dim3((unsigned)cdiv(a->ntiles - 1, kBlock)), dim3(kBlock), 0,
+                       ctx->stream, (const int64_t *)a->row_ptr, (const int64_t *)a->tile_lb, a->ntiles, fl.p,
+                       fl.p + a->ntiles, fl.p + 2 * a->ntiles, fl.p + 3 * a->ntiles,
+                       reinterpret_cast<unsigned long long *>(ctx->d_small));
+    SAMD_LAUNCH_CHECK(ctx);
+    int64_t cnt = 0;
+    SAMD_TRY(read_small(ctx, ctx->d_small, 1, &cnt));
+    a->fix_count = cnt;
+    a->fix_list = fl.release();
+  }
+  return 0;
+}
+
 // head_override: the array that receives the tiles' head sums instead of the record's own (spmv_noalloc);
 // with it nothing may be allocated here either, so a record without row_rel takes the INLINE kernels
 // (they read row_ptr itself and are valid at any size, just slower on large records).
 template <class T, class I>
 int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T *x, T *y,
-               const int32_t *tile_c0 = nullptr, T *head_override = nullptr) {
+               const int32_t *tile_c0 = nullptr, T *head_override = nullptr, bool build_nothing = false) {
   ctx->last_spmv_col_bytes = (int64_t)sizeof(I);
   const bool noalloc = head_override != nullptr;
   T *const head = noalloc ? head_override : a->head;
@@ -818,9 +836,14 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     // Small records are launch-bound: there the owner tile finishes short spills itself and the fix-up
     // launch is dropped when no row spills far.  Large records keep the fix-up launch (measured faster:
     // C2 0.238 vs 0.244 ms), so nothing is read back for them.
-    const bool inl = (a->ntiles > 1 && a->ntiles <= kInlineMaxTiles) || (noalloc && !a->row_rel);
-    SAMD_TRY(plan_stats(ctx, a));
-    if (a->max_tile_rows > kDenseRowsMax)  // some tile takes the many-empty-rows path, which writes no zeros
+    // build_nothing (a record too young to have paid for its 16-bit row offsets, see spmv_may_build): as noalloc
+    const bool inl = (a->ntiles > 1 && a->ntiles <= kInlineMaxTiles) || ((noalloc || build_nothing) && !a->row_rel);
+    // The plan's two statistics reach the host through a read-back that waits for the stream (once per record).
+    // The allocation-free entry must not wait (its callers may be capturing the stream into a graph), so on a
+    // record no ordinary product has seen yet it assumes the worst instead: y zero-filled, fix-up launch kept.
+    if (!noalloc) SAMD_TRY(plan_stats(ctx, a));
+    const bool stats = a->max_tile_rows >= 0;
+    if (!stats || a->max_tile_rows > kDenseRowsMax)  // some tile takes the many-empty-rows path, which writes no zeros
       SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));
     // gathers in flight per lane: what a typical row fragment needs (mean row length over the lanes it gets)
     int unroll = 8;
@@ -831,29 +854,7 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
       const int64_t per_lane = (avg + L - 1) / L;
       unroll = per_lane <= 6 ? 6 : 8;
     }
-    if (!inl && !a->row_rel) {
-      uint16_t *rel = nullptr;
-      SAMD_TRY(dalloc(ctx, &rel, a->n + 1));
-      hipLaunchKernelGGL(row_rel_kernel, dim3((unsigned)cdiv(a->n + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
-                         (const int64_t *)a->row_ptr, a->n, a->tile, a->ntiles, rel);
-      SAMD_LAUNCH_CHECK(ctx);
-      a->row_rel = rel;
-      // the list of rows the fix-up launch folds (one-off, one host synchronisation for its length)
-      if (a->ntiles > 1 && a->ntiles < 0x7fffffffLL) {
-        Tmp<int32_t> fl(ctx);
-        SAMD_TRY(fl.get(4 * a->ntiles));
-        SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t), ctx->stream));
-        hipLaunchKernelGGL((fixup_list_kernel<kSpmvTile>), dim3((unsigned)cdiv(a->ntiles - 1, kBlock)), dim3(kBlock), 0,
-                           ctx->stream, (const int64_t *)a->row_ptr, (const int64_t *)a->tile_lb, a->ntiles, fl.p,
-                           fl.p + a->ntiles, fl.p + 2 * a->ntiles, fl.p + 3 * a->ntiles,
-                           reinterpret_cast<unsigned long long *>(ctx->d_small));
-        SAMD_LAUNCH_CHECK(ctx);
-        int64_t cnt = 0;
-        SAMD_TRY(read_small(ctx, ctx->d_small, 1, &cnt));
-        a->fix_count = cnt;
-        a->fix_list = fl.release();
-      }
-    }
+    if (!inl && !a->row_rel) SAMD_TRY(row_rel_prepare(ctx, a));
 #define SAMD_SPMV_LAUNCH(INL, UU)                                                                                  \
   hipLaunchKernelGGL((spmv_stream_kernel<T, I, kSpmvTile, INL, UU>), dim3((unsigned)a->ntiles), dim3(kBlock), 0,   \
                      ctx->stream, (const int64_t *)a->row_ptr, col, (const T *)a->vals, x, y,                      \
@@ -875,7 +876,7 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
                            a->fix_count, (const T *)head, y);
         SAMD_LAUNCH_CHECK(ctx);
       }
-    } else if (a->ntiles > 1 && !(inl && a->spill_max <= kSpillInline)) {
+    } else if (a->ntiles > 1 && !(inl && stats && a->spill_max <= kSpillInline)) {
       hipLaunchKernelGGL((spmv_fixup_kernel<T, kSpmvTile>), dim3((unsigned)cdiv(a->ntiles - 1, kBlock)), dim3(kBlock),
                          0, ctx->stream, (const int64_t *)a->row_ptr, (const int64_t *)a->tile_lb,
                          (const T *)head, y, a->ntiles, inl);
@@ -962,6 +963,57 @@ int spmv_noalloc(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y, vo
   return spmv_typed<T, int64_t>(ctx, a, a->col64, x, y, nullptr, head);
 }
 
+// ------------------------------------------------------------ amortisation
+// Everything a record builds lazily for its products costs many products' worth of time: the two-pass copy 47 ms on
+// C3 (a product saves 1.9 ms over the plain kernel: 25 products to break even) and 146 ms on C5 (11 products), the
+// 16-bit indices of the stream path 1.2 ms on C2 (30 products).  A caller who multiplies once must not pay that, and
+// the library cannot know -- so it rents before it buys: until a record has been multiplied kBuildAfter times it is
+// served by kernels that need nothing built (the stream kernel on row_ptr / col32 as assembled), and what it has
+// spent by then on the slower kernel is about what the copies cost (the classic 2-competitive rule).  A caller who
+// knows better says so: sparse_amd_csr_*_prepare(ctx, A, expected_products) -- 1..kBuildAfter-1 pins the light path,
+// anything larger builds at once (inside prepare, so that the first product already runs at its steady state).
+// An explicit kernel request (spmv_algo, spmv_pb / spmv_reorder / spmv_cblk > 0) or option spmv_eager = 1 builds at
+// the first product, as every record did before round 3.
+constexpr int64_t kBuildAfter = 16;
+
+template <class T>
+bool spmv_may_build(futhark_context *ctx, const CsrBody<T> *a) {
+  if (ctx->opt_spmv_eager > 0 || ctx->opt_spmv_algo != 0 || ctx->opt_spmv_pb > 0 || ctx->opt_spmv_reorder > 0 ||
+      ctx->opt_spmv_cblk > 0)
+    return true;
+  const int64_t budget = a->expected_products > 0 ? a->expected_products : a->products;
+  return budget >= kBuildAfter;
+}
+
+// The per-record choices and their builds, without a product (idempotent).
+template <class T>
+int spmv_build(futhark_context *ctx, const CsrBody<T> *a) {
+  if (a->n == 0 || a->nnz == 0) return 0;
+  const int64_t algo = ctx->opt_spmv_algo;
+  if (algo != 0 && algo != 1) return 0;
+  if (a->pb_state == 0 && ctx->opt_spmv_pb > 0) SAMD_TRY(pb_prepare<T>(ctx, a, false));
+  if (a->pb_state == 1) return 0;
+  if (a->reorder_state == 0) SAMD_TRY(reorder_prepare<T>(ctx, a));  // may choose the two-pass path
+  if (a->pb_state == 1 || a->reorder_state == 1) return 0;
+  if (a->reorder_state == -1 && a->cblk_state == 0) SAMD_TRY(cblk_prepare<T>(ctx, a));
+  if (a->cblk_state == 1) return 0;
+  if (a->col16_state == 0) SAMD_TRY(col16_prepare<T>(ctx, a));
+  if (a->ntiles > kInlineMaxTiles && a->tile == kSpmvTile) {
+    SAMD_TRY(plan_stats(ctx, a));
+    SAMD_TRY(row_rel_prepare(ctx, a));
+  }
+  return 0;
+}
+
+// sparse_amd_csr_*_prepare
+template <class T>
+int spmv_prepare(futhark_context *ctx, const CsrBody<T> *a, int64_t expected_products) {
+  if (expected_products < 1) return set_error(ctx, "prepare: expected_products must be at least 1");
+  a->expected_products = expected_products;
+  if (spmv_may_build(ctx, a)) return spmv_build(ctx, a);
+  return 0;
+}
+
 // y[n] = A[n][m] x[m].  x and y are device pointers of the right lengths.
 template <class T>
 int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
@@ -970,24 +1022,24 @@ int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
     SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));  // empty row -> T.i64 0
     return 0;
   }
+  a->products++;
   const int64_t algo = ctx->opt_spmv_algo;
-  if ((algo == 0 || algo == 1) && a->tb_state == 0 && ctx->opt_spmv_2d > 1) SAMD_TRY(tb_prepare<T>(ctx, a, false));
-  if ((algo == 0 || algo == 1) && a->tb_state == 1) { ctx->last_spmv_path = 4; return spmv_2d<T>(ctx, a, x, y); }
-  if ((algo == 0 || algo == 1) && a->pb_state == 0 && ctx->opt_spmv_pb > 0) SAMD_TRY(pb_prepare<T>(ctx, a, false));
-  if ((algo == 0 || algo == 1) && a->pb_state == 1) { ctx->last_spmv_path = 3; return spmv_pb<T>(ctx, a, x, y); }
-  if ((algo == 0 || algo == 1) && a->reorder_state == 0) SAMD_TRY(reorder_prepare<T>(ctx, a));  // may choose the 2-D or the two-pass path
-  if ((algo == 0 || algo == 1) && a->tb_state == 1) { ctx->last_spmv_path = 4; return spmv_2d<T>(ctx, a, x, y); }
-  if ((algo == 0 || algo == 1) && a->pb_state == 1) { ctx->last_spmv_path = 3; return spmv_pb<T>(ctx, a, x, y); }
+  const bool auto_algo = algo == 0 || algo == 1;
+  const bool build = spmv_may_build(ctx, a);  // whatever is built already is used either way
+  if (auto_algo && a->pb_state == 0 && ctx->opt_spmv_pb > 0) SAMD_TRY(pb_prepare<T>(ctx, a, false));
+  if (auto_algo && a->pb_state == 1) { ctx->last_spmv_path = 3; return spmv_pb<T>(ctx, a, x, y); }
+  if (auto_algo && build && a->reorder_state == 0) SAMD_TRY(reorder_prepare<T>(ctx, a));  // may choose the two-pass path
+  if (auto_algo && a->pb_state == 1) { ctx->last_spmv_path = 3; return spmv_pb<T>(ctx, a, x, y); }
   ctx->last_spmv_path = 0;
-  if ((algo == 0 || algo == 1) && a->reorder_state == 1) {
+  if (auto_algo && a->reorder_state == 1) {
     ctx->last_spmv_path = 1;
     hipLaunchKernelGGL((reorder_gather_x_kernel<T>), dim3((unsigned)cdiv(a->m, kBlock)), dim3(kBlock), 0, ctx->stream,
                        x, (const uint32_t *)a->hot_perm, a->m, a->x_hot);
     SAMD_LAUNCH_CHECK(ctx);
     return spmv_typed<T, int32_t>(ctx, a, a->col_hot, (const T *)a->x_hot, y);
   }
-  if ((algo == 0 || algo == 1) && a->reorder_state == -1 && a->cblk_state == 0) SAMD_TRY(cblk_prepare<T>(ctx, a));
-  if ((algo == 0 || algo == 1) && a->cblk_state == 1) {
+  if (auto_algo && build && a->reorder_state == -1 && a->cblk_state == 0) SAMD_TRY(cblk_prepare<T>(ctx, a));
+  if (auto_algo && a->cblk_state == 1) {
     ctx->last_spmv_path = 2;
     const int64_t panels = cdiv(a->n, kCblkRows);
     for (int64_t b = 0; b < a->cblk_nb; b++) {
@@ -998,11 +1050,11 @@ int spmv(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
     }
     return 0;
   }
-  if ((algo == 0 || algo == 1) && a->col16_state == 0) SAMD_TRY(col16_prepare<T>(ctx, a));
-  if ((algo == 0 || algo == 1) && a->col16_state == 1)
+  if (auto_algo && build && a->col16_state == 0) SAMD_TRY(col16_prepare<T>(ctx, a));
+  if (auto_algo && a->col16_state == 1 && (build || a->row_rel))
     return spmv_typed<T, uint16_t>(ctx, a, (const uint16_t *)a->col16, x, y, (const int32_t *)a->tile_c0);
-  if (a->col32) return spmv_typed<T, int32_t>(ctx, a, a->col32, x, y);
-  return spmv_typed<T, int64_t>(ctx, a, a->col64, x, y);
+  if (a->col32) return spmv_typed<T, int32_t>(ctx, a, a->col32, x, y, nullptr, nullptr, !build);
+  return spmv_typed<T, int64_t>(ctx, a, a->col64, x, y, nullptr, nullptr, !build);
 }
 
 }  // namespace samd

@@ -429,6 +429,14 @@ class DistCsr:
         D.bounds = list(bounds)
         return D
 
+    def prepare(self, expected_products):
+        """How many products will follow (sparse_amd_csr_*_prepare on this rank's records): a solver says a large
+        number and the records build their faster SpMV forms now instead of at their 16th product."""
+        self.M.sr.prepare(self.A, expected_products)
+        if self.A_gh is not None:
+            self.M.sr.prepare(self.A_gh, expected_products)
+        return self
+
     def nnz_offset(self):
         """Stored entries on lower ranks (one all-gather of a scalar per rank)."""
         import torch

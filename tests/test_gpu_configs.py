@@ -22,6 +22,7 @@ def env():
     import torch
     from sparse_amd import Context
     ctx = Context(0)
+    ctx.set_option("spmv_eager", 1)      # these tests look at the per-record SpMV forms: built at the first product, not the 16th
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     yield torch, ctx
     torch.cuda.synchronize()

@@ -11,6 +11,7 @@ def setup():
     import torch
     from sparse_amd import Context, mk_compressed, synth
     ctx = Context(0)
+    ctx.set_option("spmv_eager", 1)      # these tests look at the per-record SpMV forms: built at the first product, not the 16th
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     M = mk_compressed("f64", ctx)
     g = 4096
@@ -101,6 +102,7 @@ def _ctx():
     import torch
     from sparse_amd import Context
     ctx = Context(0)
+    ctx.set_option("spmv_eager", 1)      # these tests look at the per-record SpMV forms: built at the first product, not the 16th
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     return torch, ctx
 

@@ -1,7 +1,8 @@
 """The native multi-GPU API (include/sparse_amd.h section 6) through the C ABI.  One GPU is all a test box has,
 so several members share device 0 over the peer transport (direct copies ordered by events -- the same code
-path distinct devices take when RCCL is not asked for); the RCCL transport itself needs distinct devices and is
-exercised by a one-member group only (no exchange).  Checked: the members' records are, bit for bit, the row
+path distinct devices take when RCCL is not asked for); the RCCL transport itself needs distinct devices, so what
+a one-GPU box can run of it is a one-member group named "rccl": librccl opened, ncclCommInitAll, and the member's
+slice of x moved by a grouped ncclSend / ncclRecv to itself (test_rccl_transport_runs_on_one_member).  Checked: the members' records are, bit for bit, the row
 blocks of the oracle's single record (duplicates summed in input order); y = A x against the oracle; a chain of
 products whose result is the next operand (square matrices: x is cut like the rows)."""
 import numpy as np
@@ -63,7 +64,9 @@ def test_group_errors_and_transport_choice():
         Group([0, 0], "rccl")
     with pytest.raises(SparseError, match="transport"):
         Group([0], "carrier-pigeon")
-    g = Group([0], "rccl")                                # one member: nothing to exchange, librccl is not even opened
+    with pytest.raises(SparseError, match="members"):     # the group object still comes back, with the text in it
+        Group([], None)
+    g = Group([0], None)                                  # one member, nothing asked for: librccl is not even opened
     assert g.transport == "none"
     with pytest.raises(SparseError, match="out of bounds"):
         g.sparse(3, 3, (np.array([3]), np.array([0]), np.array([1.0])))
@@ -88,3 +91,28 @@ def test_c_caller_shards_without_python():
         out = subprocess.run([exe] + args, capture_output=True, timeout=100)
         assert out.returncode == 0, out.stderr.decode()
         assert b"group ok" in out.stdout
+
+
+def test_rccl_transport_runs_on_one_member():
+    """group.hpp's RCCL path end to end on the one GPU there is: dlopen(librccl), ncclCommInitAll over one device,
+    and every product's x slice travelling through ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd to itself
+    on the member's stream, followed by the ordinary product.  y against the oracle; x_full is overwritten between
+    products so a transfer that silently did nothing would show."""
+    from sparse_amd.group import Group
+    g = Group([0], "rccl")
+    assert g.transport == "rccl" and g.size == 1
+    O = Oracle("f64")
+    n, m, k = 6000, 7000, 150000
+    r, c, v = random_coo(n, m, k, "f64", seed=21, dup_frac=0.05)
+    Ao = O.sr_sparse(n, m, r, c, v)
+    A = g.sparse(n, m, (r, c, v))
+    yv = g.vector(A, None, like_rows=True)
+    for seed in (31, 32, 33):
+        x = synth.uniform_values(seed, m, "f64")
+        xv = g.vector(A, x)
+        g.smvm(yv, A, xv)
+        np.testing.assert_allclose(yv.numpy(), O.sr_smvm(Ao, x), rtol=1e-12, atol=0)
+        xv.free()
+    for o in (yv, A):
+        o.free()
+    g.close()

@@ -25,6 +25,7 @@ RTOL = {"f64": 1e-12, "f32": 1e-5, "i32": 0}
 def ctx():
     from sparse_amd import Context
     c = Context(0)
+    c.set_option("spmv_eager", 1)      # these tests look at the per-record SpMV forms: built at the first product, not the 16th
     yield c
     c.sync()
 
@@ -124,8 +125,8 @@ def test_sparse_edge_cases(ctx, dtype):
     ev = np.zeros(0, NP[dtype])
     for n, m in ((2, 3), (0, 0), (0, 4), (4, 0), (1, 1)):
         assert_same_record(M.sr.sparse(n, m, (e, e, ev)), O.sr_sparse(n, m, e, e, ev))
-    # every triple the same coordinate: one long run, folded left to right
-    k = 5000
+    # every triple the same coordinate: one run, folded left to right (kLongRun = 4096 pairs is where a workgroup takes over)
+    k = 4096
     r, c = np.full(k, 3, np.int64), np.full(k, 1, np.int64)
     v = synth.uniform_values(1, k, dtype)
     assert_same_record(M.sr.sparse(5, 2, (r, c, v)), O.sr_sparse(5, 2, r, c, v))
@@ -144,6 +145,74 @@ def test_sparse_edge_cases(ctx, dtype):
     c = (synth.splitmix64(6, np.arange(3000, dtype=np.uint64)) % np.uint64(m)).astype(np.int64)
     v = synth.uniform_values(7, 3000, dtype)
     assert_same_record(M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
+@pytest.mark.parametrize("algo", [0, 1], ids=["fold_emit", "scan_merge_emit"])
+def test_sparse_long_runs_of_one_coordinate_are_summed_by_a_workgroup(ctx, dtype, algo):
+    """merge_coo (compressed.fut:76-84) when one coordinate repeats more than kLongRun = 4096 times: the run leaves
+    the one-thread left-to-right fold and is summed by a workgroup (fold_long_runs_kernel).  Index arrays and every
+    short run stay bit-equal to the oracle; the long runs are exact for i32 and within the bars for floats (the
+    reference's segmented_reduce fixes no order).  Runs of 4097 (just over), 20 000 and 300 000, one of them at the
+    very end of the input, next to ordinary entries; both emission paths (sort_algo 1 = scan + merge_emit)."""
+    n, m = 3000, 2000
+    r, c, v = random_coo(n, m, 60000, dtype, seed=71, dup_frac=0.1)
+    runs = [(5, 7, 4097), (1234, 0, 20000), (n - 1, m - 1, 300000)]
+    rr = np.concatenate([r] + [np.full(k, a, np.int64) for a, b, k in runs])
+    cc = np.concatenate([c] + [np.full(k, b, np.int64) for a, b, k in runs])
+    vv = np.concatenate([v] + [synth.uniform_values(72 + i, k, dtype) for i, (a, b, k) in enumerate(runs)])
+    perm = np.argsort(synth.splitmix64(73, np.arange(len(rr), dtype=np.uint64)), kind="stable")   # shuffled input
+    rr, cc, vv = rr[perm], cc[perm], vv[perm]
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    want = O.sr_sparse(n, m, rr, cc, vv)
+    ctx.set_option("sort_algo", algo)
+    try:
+        A = M.sr.sparse(n, m, (rr, cc, vv))
+        if algo == 0:
+            assert ctx.get_option("sort_last_long_runs") == 3
+    finally:
+        ctx.set_option("sort_algo", 0)
+    ro, ci, va = fields(A)
+    assert np.array_equal(ro, want["row_off"]) and np.array_equal(ci, want["col_idx"])
+    pos = [int(want["row_off"][a - 1] if a else 0) + int(np.searchsorted(ci[(want["row_off"][a - 1] if a else 0):want["row_off"][a]], b))
+           for a, b, k in runs]
+    short = np.ones(len(va), bool)
+    short[pos] = False
+    assert np.array_equal(va[short], want["vals"][short]), "a short run lost its left-to-right sum"
+    if dtype == "i32":
+        assert np.array_equal(va[pos], want["vals"][pos])
+    else:
+        # the workgroup's sum against the exactly rounded one (math.fsum); the oracle's one-at-a-time f32 sum is the
+        # less accurate of the two on 300 000 terms, so it is the oracle that gets the looser look here
+        import math
+        for p_, (a, b, k) in zip(pos, runs):
+            sel = (rr == a) & (cc == b)
+            exact = math.fsum(vv[sel].astype(np.float64))
+            assert abs(float(va[p_]) - exact) <= RTOL[dtype] * abs(exact), (dtype, k, float(va[p_]), exact)
+        np.testing.assert_allclose(va[pos], want["vals"][pos], rtol=1e-12 if dtype == "f64" else 2e-3, atol=0)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "i32"])
+def test_sparse_one_coordinate_repeated_ten_million_times(ctx, dtype):
+    """The bounded fold at the size the one-thread loop could not survive: 10^7 triples on ONE coordinate plus a
+    few others.  i32 exact (wrapping sums commute); f64 within 1e-12 of the oracle's left-to-right sum."""
+    import time
+    k = 10 ** 7
+    rr = np.concatenate([np.full(k, 2, np.int64), np.array([0, 4, 2], np.int64)])
+    cc = np.concatenate([np.full(k, 1, np.int64), np.array([0, 2, 0], np.int64)])
+    vv = synth.uniform_values(81, k + 3, dtype)
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    want = O.sr_sparse(5, 3, rr, cc, vv)
+    dr, dc, dv = ctx.array(rr, "i64"), ctx.array(cc, "i64"), ctx.array(vv, dtype)
+    M.sr.sparse(5, 3, (dr, dc, dv))                              # warm: pool and code objects
+    ctx.sync()
+    t0 = time.perf_counter()
+    A = M.sr.sparse(5, 3, (dr, dc, dv))
+    ctx.sync()
+    ms = (time.perf_counter() - t0) * 1e3
+    assert ctx.get_option("sort_last_long_runs") == 1
+    assert_same_record(A, want, exact_vals=(dtype == "i32"), dtype=dtype)
+    assert ms < 50, "assembly of 1e7 equal coordinates took %.1f ms" % ms
 
 
 @pytest.mark.parametrize("dtype,indirect", [("f64", 1), ("f64", -1), ("f32", 0), ("i32", 0)])
@@ -399,48 +468,6 @@ def test_smvm_two_pass_panels(ctx, dtype, geom, fold):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
-@pytest.mark.parametrize("geom", [(0, 0, 0, 0), (64, 64, 512, 8), (700, 160, 4096, 40), (300, 32, 100000, 1)],
-                         ids=["one_panel", "tiny", "mid", "all_dense"])
-def test_smvm_2d_blocks(ctx, dtype, geom):
-    """spmv_2d=2 forces the 2-D blocked product (normally kept for large, wide, skewed records of 4-byte values):
-    columns renumbered by popularity, entries regrouped into (row panel) x (column block) pieces; the x slice
-    of a well-filled piece and the panel's y slice sit in LDS together, thinly filled pieces gather from global
-    memory; a heavy panel is cut into units whose sums meet in a small buffer.  The overrides (rows per panel,
-    columns per block, entries per unit, entries that make a piece dense) shrink the geometry so that small
-    records have many panels, blocks, units and both kinds of piece.  Against the oracle within the dtype's bar
-    (another summation order), i32 exact; a second x on the cached copy; a dense row, empty rows, one column,
-    one row, column numbers beyond the first blocks; the record itself untouched."""
-    O, M = Oracle(dtype), mk(ctx, dtype)
-    rows, cols, entries, dense = geom
-    ctx.set_option("spmv_2d", 2)
-    ctx.set_option("spmv_2d_rows", rows)
-    ctx.set_option("spmv_2d_cols", cols)
-    ctx.set_option("spmv_2d_entries", entries)
-    ctx.set_option("spmv_2d_dense", dense)
-    try:
-        for n, m, gen in ((3000, 9000, lambda: skewed_coo(3000, 9000, dtype, 8)),
-                          (20000, 5000, lambda: random_coo(20000, 5000, 90000, dtype, seed=91, dup_frac=0.05)),
-                          (1, 7000, lambda: random_coo(1, 7000, 6000, dtype, seed=93)),
-                          (6000, 1, lambda: random_coo(6000, 1, 900, dtype, seed=94)),
-                          (700, 6000, lambda: tuple(a if i != 1 else a + 1500 for i, a in
-                                                    enumerate(random_coo(700, 4500, 20000, dtype, seed=92))))):
-            r, c, v = gen()
-            A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
-            x = synth.uniform_values(5, m, dtype)
-            y = ctx.array(np.full(n, 7, NP[dtype]), dtype)       # every row must be written, also the empty ones
-            M.sr.smvm_into(y, A, x)
-            assert ctx.get_option("spmv_last_path") == 4
-            close(y.numpy(), O.sr_smvm(Ao, x), dtype)
-            x2 = synth.uniform_values(6, m, dtype)
-            close(M.sr.smvm(A, x2), O.sr_smvm(Ao, x2), dtype)
-            close(M.sr.smvm(A, x), O.sr_smvm(Ao, x), dtype)       # the buffer of the cut panels was left clean
-            assert_same_record(A, Ao)
-    finally:
-        for k in ("spmv_2d", "spmv_2d_rows", "spmv_2d_cols", "spmv_2d_entries", "spmv_2d_dense"):
-            ctx.set_option(k, 0)
-
-
-@pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])
 def test_smvm_16_bit_columns_and_row_offsets_on_a_large_banded_record(ctx, dtype):
     """Records of more than 4096 tiles read 16-bit tile-relative row offsets, and 16-bit tile-relative columns
     when every tile spans fewer than 65536 columns (banded / stencil).  Against the oracle; bit-identical to the
@@ -603,6 +630,82 @@ def test_smvm_into_caller_storage(ctx, dtype):
         M.sr.smvm_into(big, A, x, rows[:-1])
 
 
+@pytest.mark.parametrize("kind", ["banded", "random_wide"])
+def test_smvm_builds_nothing_until_the_16th_product_unless_told(kind):
+    """Amortisation (spmv.hpp: spmv_may_build; sparse_amd_csr_*_prepare).  A large record's faster SpMV forms
+    (16-bit indices for a banded record, the two-pass copy for a wide random one) cost many products' worth of time.
+    Default: the first 15 products run on what the assembly left (col32 / row_ptr: 4-byte columns, path 0) and the
+    pool does not grow; the 16th builds.  prepare(A, n >= 16) builds at once, prepare(A, 1) never.  Every product
+    against the oracle."""
+    import re
+    from sparse_amd import Context
+    c = Context(0)                                                    # default options: no spmv_eager
+    O, M = Oracle("f64"), mk(c, "f64")
+    if kind == "banded":
+        n = m = 700000
+        per = 7
+        i = np.arange(n, dtype=np.int64)
+        r = np.repeat(i, per)
+        cc = np.minimum(np.repeat(i, per) + np.tile(np.arange(per, dtype=np.int64), n), m - 1)
+        built = lambda: c.get_option("spmv_last_col_bytes") == 2
+    else:
+        n, m = 40000, 1 << 23                                           # x = 64 MB of f64: gather-bound, flat popularity
+        k = 6000000
+        r = (synth.splitmix64(91, np.arange(k, dtype=np.uint64)) % np.uint64(n)).astype(np.int64)
+        cc = (synth.splitmix64(92, np.arange(k, dtype=np.uint64)) % np.uint64(m)).astype(np.int64)
+        built = lambda: c.get_option("spmv_last_path") in (2, 3)
+    v = synth.uniform_values(93, len(r), "f64")
+    Ao = O.sr_sparse(n, m, r, cc, v)
+    x = synth.uniform_values(94, m, "f64")
+    want = O.sr_smvm(Ao, x)
+    xd = c.array(x, "f64")
+    yd = c.array(np.zeros(n), "f64")
+
+    def held():
+        return int(re.search(r"device memory held: (\d+) bytes", c.report()).group(1))
+
+    def check():
+        np.testing.assert_allclose(yd.numpy(), want, rtol=1e-12, atol=0)
+
+    # (1) no hint: light until the 16th product
+    A = M.sr.sparse(n, m, (r, cc, v))
+    c.sync()
+    before = held()
+    for i in range(15):
+        M.sr.smvm_into(yd, A, xd)
+        assert c.get_option("spmv_last_path") == 0 and c.get_option("spmv_last_col_bytes") == 4, i
+    check()
+    assert held() == before, "a product before the 16th built something"
+    M.sr.smvm_into(yd, A, xd)                                         # the 16th
+    assert built()
+    check()
+    assert held() > before
+    # (2) told at once
+    B = M.sr.sparse(n, m, (r, cc, v))
+    M.sr.prepare(B, 1000)
+    grown = held()
+    M.sr.smvm_into(yd, B, xd)
+    assert built()
+    check()
+    assert held() == grown, "the first product after prepare still built something"
+    # (3) told it is a one-off: never built, however often it is multiplied after all
+    C = M.sr.sparse(n, m, (r, cc, v))
+    M.sr.prepare(C, 1)
+    for i in range(20):
+        M.sr.smvm_into(yd, C, xd)
+    assert not built() and c.get_option("spmv_last_path") == 0
+    check()
+    with pytest.raises(Exception, match="expected_products"):
+        M.sr.prepare(C, 0)
+    # the csc label of the same record (vsmm, compressed.fut:223-224)
+    T = M.sr.transpose(C)
+    M.sc.prepare(T, 1000)
+    np.testing.assert_allclose(M.sc.vsmm(x, T).numpy(), want, rtol=1e-12, atol=0)
+    assert built()
+    c.sync()
+    c.close()
+
+
 def test_smvm_is_reproducible(ctx):
     M = mk(ctx, "f64")
     r, c, v = skewed_coo(3000, 9000, "f64", 8)
@@ -643,6 +746,38 @@ def test_coo_dense_nnz_scale_addsub_conversion(ctx, dtype):
     # zero-cost transpose: same record, other label
     assert_same_record(M.sr.transpose(A), Ao)
     assert np.array_equal(M.sc.dense(M.sr.transpose(A)).numpy(), O.sr_dense(Ao).T)
+
+
+@pytest.mark.parametrize("tiles,big", [(1, False), (3, False), (5000, True)])
+def test_coo_conversion_addsub_when_entries_fill_whole_tiles_and_empty_rows_trail(ctx, tiles, big):
+    """A record whose entry count is a multiple of the tile size (1024) and whose last rows are empty: those rows
+    start at offset 1024 of the last tile, one past the row marks a tile's workgroup keeps in LDS (tile_rows:
+    sr.coo, the key packing of the conversions -- with and without digit counts, i.e. small and large records --
+    and of + / -).  Every operation against the oracle."""
+    dtype = "f64"
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    nnz = tiles * 1024
+    per = 8
+    n_full = nnz // per
+    n, m = n_full + 300, n_full + per
+    i = np.arange(n_full, dtype=np.int64)
+    r = np.repeat(i, per)
+    c = np.repeat(i, per) + np.tile(np.arange(per, dtype=np.int64), n_full)
+    v = synth.uniform_values(61, nnz, dtype)
+    A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
+    assert A.stored_dims()[2] == nnz and Ao["row_off"][-1] == nnz and Ao["row_off"][n_full - 1] == nnz
+    for got, want in zip(M.sr.coo(A), O.sr_coo(Ao)):
+        assert np.array_equal(np.asarray(got), want)
+    T = M.sr.to_sc(A)
+    assert_same_record(T, O.sr_to_sc(Ao))
+    assert_same_record(M.sc.to_sr(T), Ao)
+    if not big:
+        assert_same_record(M.sr.add(A, A), O.sr_add(Ao, Ao))
+        assert_same_record(M.sr.sub(A, M.sr.eye(n, m)), O.sr_sub(Ao, O.sr_eye(n, m)))
+    else:
+        S = M.sr.add(A, A)
+        ro, ci, va = (np.asarray(f) for f in S.fields())
+        assert np.array_equal(ro, Ao["row_off"]) and np.array_equal(ci, Ao["col_idx"]) and np.array_equal(va, 2 * Ao["vals"])
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32", "i32"])

@@ -23,6 +23,7 @@ RTOL = {"f64": 1e-12, "f32": 1e-5, "i32": 0}
 def ctx():
     from sparse_amd import Context
     c = Context(0)
+    c.set_option("spmv_eager", 1)      # these tests look at the per-record SpMV forms: built at the first product, not the 16th
     yield c
     c.sync()
 
@@ -125,3 +126,50 @@ def test_noalloc_rejects_a_record_beyond_the_static_array(ctx):
                 assert np.all(y.numpy() == 7.0)
     finally:
         ctx.set_option("noalloc_scratch_bytes", 0)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "i32"])
+def test_noalloc_is_legal_under_graph_capture_on_a_fresh_record(dtype):
+    """What the header offers the entry point for: a caller capturing its stream into a HIP graph.  The record has
+    had no product yet (so nothing about it has been read back), the call sits between BeginCapture and EndCapture
+    of the stream the context has adopted (torch.cuda.graph), and the graph is then replayed on two different
+    operands.  y against the ORACLE.  The matrix has rows crossing tile ends, rows longer than a tile and a run of
+    empty rows, i.e. every fix-up case; a call that waited for the stream or allocated would invalidate the capture."""
+    import torch
+    from oracle.oracle import Oracle
+    from sparse_amd import Context, mk_compressed
+    ctx = Context(0)
+    M, O = mk_compressed(dtype, ctx), Oracle(dtype)
+    n, m = 40000, 30000
+    r, c, v = random_coo(n, m, 500000, dtype, seed=41)
+    keep = (r < 9000) | (r >= 13000)                       # 4000 empty rows in a run
+    r, c, v = r[keep], c[keep], v[keep]
+    lr = np.full(3000, 17, np.int64)                        # one row of ~3000 entries: spans three tiles
+    lc = np.arange(3000, dtype=np.int64) * 7 % m
+    r, c = np.concatenate([r, lr]), np.concatenate([c, lc])
+    v = np.concatenate([v, synth.uniform_values(42, 3000, dtype)])
+    A, Ao = M.sr.sparse(n, m, (r, c, v)), O.sr_sparse(n, m, r, c, v)
+    ctx.sync()
+    tdt = {"f64": torch.float64, "i32": torch.int32}[dtype]
+    x1, x2 = synth.uniform_values(43, m, dtype), synth.uniform_values(44, m, dtype)
+    dev = torch.device("cuda", 0)
+    xt = torch.as_tensor(x1, device=dev).contiguous()
+    yt = torch.full((n,), 7, dtype=tdt, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    ctx.set_stream(s.cuda_stream)
+    xh, yh = ctx.array(xt, dtype), ctx.array(yt, dtype)     # wrapped in place: no device memory is taken
+    before = held_bytes(ctx)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        M.sr.smvm_into_noalloc(yh, A, xh)
+    assert held_bytes(ctx) == before
+    for x in (x1, x2):
+        xt.copy_(torch.as_tensor(x, device=dev))
+        yt.fill_(7)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        close(yt.cpu().numpy(), O.sr_smvm(Ao, x), dtype)
+    del g
+    ctx.set_stream(None)
+    ctx.sync()
