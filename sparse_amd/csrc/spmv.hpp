@@ -790,6 +790,23 @@ int plan_stats(futhark_context *ctx, const CsrBody<T> *a) {
   return 0;
 }
 
+// y = 0 by a kernel of the library's own.  The allocation-free entry uses it instead of hipMemsetAsync: captured into
+// a graph, that memset came back as something else than zeros on replay (ROCm 7.0 runtime under torch.cuda.graph:
+// the zero-filled rows of tests/test_zz_no_alloc.py read 4.3e-310), and a kernel node is what the rest of the call is.
+template <class T>
+__global__ __launch_bounds__(kBlock) void zero_fill_kernel(T *__restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) y[i] = (T)0;
+}
+
+template <class T>
+int zero_fill(futhark_context *ctx, T *y, int64_t n) {
+  if (n <= 0) return 0;
+  const int64_t want = cdiv(n, kBlock), cap = (int64_t)ctx->num_cu * 16;
+  hipLaunchKernelGGL((zero_fill_kernel<T>), dim3((unsigned)(want < cap ? want : cap)), dim3(kBlock), 0, ctx->stream, y, n);
+  SAMD_LAUNCH_CHECK(ctx);
+  return 0;
+}
+
 // 16-bit tile-relative row offsets and the list of rows the fix-up launch folds, for the stream kernel on large
 // records (one-off, one host synchronisation for the list's length)
 template <class T>
@@ -843,8 +860,10 @@ int spmv_typed(futhark_context *ctx, const CsrBody<T> *a, const I *col, const T 
     // record no ordinary product has seen yet it assumes the worst instead: y zero-filled, fix-up launch kept.
     if (!noalloc) SAMD_TRY(plan_stats(ctx, a));
     const bool stats = a->max_tile_rows >= 0;
-    if (!stats || a->max_tile_rows > kDenseRowsMax)  // some tile takes the many-empty-rows path, which writes no zeros
-      SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));
+    if (!stats || a->max_tile_rows > kDenseRowsMax) {  // some tile takes the many-empty-rows path, which writes no zeros
+      if (noalloc) SAMD_TRY(zero_fill(ctx, y, a->n));
+      else SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));
+    }
     // gathers in flight per lane: what a typical row fragment needs (mean row length over the lanes it gets)
     int unroll = 8;
     {
@@ -946,10 +965,7 @@ int spmv_rows_add_small(futhark_context *ctx, const CsrBody<T> *a, const T *x, T
 template <class T>
 int spmv_noalloc(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y, void *scratch, size_t scratch_bytes) {
   if (a->n == 0) return 0;
-  if (a->nnz == 0) {
-    SAMD_HIP(ctx, hipMemsetAsync(y, 0, sizeof(T) * (size_t)a->n, ctx->stream));
-    return 0;
-  }
+  if (a->nnz == 0) return zero_fill(ctx, y, a->n);
   if (!scratch) return set_error(ctx, "smvm_into_noalloc: the static scratch array is not available on this device");
   if ((size_t)a->ntiles * sizeof(T) > scratch_bytes)
     return set_error(ctx, "smvm_into_noalloc: record of %lld entries needs %zu bytes of scratch, the static array holds %zu "
