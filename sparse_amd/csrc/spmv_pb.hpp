@@ -502,8 +502,80 @@ __device__ __forceinline__ P *pb_uniform_ptr(P *p) {  // p is the same in every 
   return (P *)(G *)(((uint64_t)hi << 32) | lo);
 }
 
+// ---- buffer addressing for pass 1's streams.  A global load or store through a 64-bit vector address costs a
+// 64-bit vector add per access (v_lshl_add_u64, not a full-rate instruction), and pass 1 is bound by vector issue:
+// 36 vector instructions per 64 entries, 10 of them address arithmetic.  Buffer instructions take a scalar
+// descriptor (the base moves with the step: scalar adds, which issue beside the vector ones), one 32-bit lane offset
+// that never changes, and an immediate: no vector instruction per load at all, three (and, bcnt + base, shift) per
+// store.  The descriptors are raw (stride 0) with the range check out of the way: every offset is in range by
+// construction of the layout.
+typedef unsigned int pb_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kPbRsrcFlags = 0x00020000;  // gfx9 raw buffer, 32-bit data format
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pb_rsrc(const void *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffffe, kPbRsrcFlags);
+}
+template <int AUX>
+__device__ __forceinline__ float pb_bload(__amdgpu_buffer_rsrc_t r, int off, const float *) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ int32_t pb_bload(__amdgpu_buffer_rsrc_t r, int off, const int32_t *) {
+  return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ double pb_bload(__amdgpu_buffer_rsrc_t r, int off, const double *) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void pb_bstore(float v, __amdgpu_buffer_rsrc_t r, int off) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void pb_bstore(int32_t v, __amdgpu_buffer_rsrc_t r, int off) {
+  __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, r, off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void pb_bstore(double v, __amdgpu_buffer_rsrc_t r, int off) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pb_u32x2, v), r, off, 0, AUX);
+}
+
+// the run sums of one instruction's 64 products; h: this lane's half of the heads mask.  As pb_run_sum, on 32-bit
+// masks only (a 64-bit vector shift per use is what the compiler makes of `lane < 32 ? lo : hi` otherwise).
+template <class T>
+__device__ __forceinline__ T pb_run_sum32(T p, bool all_heads, uint32_t h, const PbLane &L) {
+  if (all_heads) return p;  // every run is one entry (the thin part of the matrix)
+  const int dist = L.l5 - 31 + __builtin_clz(h & L.upto);  // distance to the run's first lane
+  {
+    const T t = pb_dpp0<0x111, 0xf>(p);  // row_shr:1
+    if (dist >= 1) p = (T)(p + t);
+  }
+  if (__ballot(dist >= 2) != 0ull) {
+    {
+      const T t = pb_dpp0<0x112, 0xf>(p);
+      if (dist >= 2) p = (T)(p + t);
+    }
+    if (__ballot(dist >= 4) != 0ull) {
+      {
+        const T t = pb_dpp0<0x114, 0xf>(p);
+        if (dist >= 4) p = (T)(p + t);
+      }
+      {
+        const T t = pb_dpp0<0x118, 0xf>(p);
+        if (dist >= 8) p = (T)(p + t);
+      }
+    }
+  }
+  if (kPbRunCap > 16) {  // a run that began in the 16 lanes before this row: lane 15 of that row holds its part there
+    const T t = pb_dpp0<0x142, 0xa>(p);  // row_bcast:15 into rows 1 and 3
+    if (dist > (L.lane & 15)) p = (T)(p + t);
+  }
+  return p;
+}
+
 // LAB (kernel lab; results wrong for 1, 2, 4): 1 no store, 2 no LDS gather, 3 non-temporal stores, 4 no run sums
-template <class T, int U, int LAB>
+// WIDE: the products do not fit a 32-bit byte offset (2^32 / sizeof(T) outputs and more): stores through 64-bit addresses
+template <class T, int U, int LAB, bool WIDE>
 __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__restrict__ wtab,
                                                                const uint16_t *__restrict__ col16,
                                                                const T *__restrict__ pval, const T *__restrict__ xperm,
@@ -522,22 +594,20 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
   constexpr int kChunk = 64 * U;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const PbLane L(lane);
+  const int off_c = lane * 2, off_v = lane * (int)sizeof(T), off_g = (lane >> 5) * 4;  // the lane offsets of a step's three streams
+  const __amdgpu_buffer_rsrc_t rprod = pb_rsrc(prod);
   __syncthreads();
   // A wavefront takes 64 U consecutive entries per step: runs are neighbouring lanes.  s, e and every step are
   // multiples of 32, so lanes 0 and 32 always sit on a forced run start.  The next step's entries are requested
-  // before the current one's runs are summed (the sums are ~30 vector instructions per 64 entries).
-  // (32-bit registers for the 16-bit columns: packed pairs would make each load wait for its neighbour; base
-  // addresses pinned to scalar registers: otherwise the compiler folds the lane offset into a loop-invariant 64-bit
-  // vector base and spends four vector instructions per load on the address)
-  auto load = [&](int64_t cs, uint32_t (&c)[U], T (&v)[U], uint32_t (&g)[U]) {  // a whole step
-    const uint16_t *cp = pb_uniform_ptr(col16 + cs);  // cs is the same in every lane
-    const T *vp = pb_uniform_ptr(pval + cs);
-    const uint32_t *gp = pb_uniform_ptr(uout + (cs >> 5));
+  // before the current one's runs are summed (the sums are ~25 vector instructions per 64 entries).
+  // (32-bit registers for the 16-bit columns: packed pairs would make each load wait for its neighbour)
+  auto load = [&](int64_t cs, uint32_t (&c)[U], T (&v)[U], uint32_t (&g)[U]) {  // a whole step; cs is the same in every lane
+    const __amdgpu_buffer_rsrc_t rc = pb_rsrc(col16 + cs), rv = pb_rsrc(pval + cs), rg = pb_rsrc(uout + (cs >> 5));
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      c[u] = (uint32_t)ntload(cp + (unsigned)(u * 64 + lane));
-      v[u] = ntload(vp + (unsigned)(u * 64 + lane));
-      g[u] = gp[(unsigned)(u * 2 + (lane >> 5))];
+      c[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rc, off_c + u * 128, 0, 2);  // aux 2: non-temporal
+      v[u] = pb_bload<2>(rv, off_v + u * 64 * (int)sizeof(T), (const T *)nullptr);
+      g[u] = __builtin_amdgcn_raw_buffer_load_b32(rg, off_g + u * 8, 0, 0);
     }
   };
   // The sums are stored where they fall, a group's few at a time: short, unaligned pieces of lines, which the memory
@@ -556,12 +626,22 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
     for (int u = 0; u < U; u++) {
       const bool ok = u * 64 + lane < n;
       const unsigned long long heads = __ballot(!ok || (c[u] & 0x8000) != 0);
-      const T sum = LAB == 4 ? pr[u] : pb_run_sum<T>(pr[u], heads, L);
-      const uint32_t tails = L.half(heads >> 1) | (L.hi ? 0x80000000u : 0u);  // bit 31 of the low half: lane 32 starts a run
+      // this lane's half of the mask, picked from two scalars (bit 32 is always set: lane 32 starts a run)
+      const uint32_t hlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)heads);
+      const uint32_t hhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(heads >> 32));
+      const uint32_t h = L.hi ? hhi : hlo;
+      const T sum = LAB == 4 ? pr[u] : pb_run_sum32<T>(pr[u], heads == ~0ull, h, L);
+      const uint32_t tails = (h >> 1) | 0x80000000u;  // a run ends where the next lane starts one, and at the end of its half
       if (ok && (tails & L.bit) != 0) {
-        T *d = prod + ((int64_t)g[u] + __popc(tails & L.under));
-        if (LAB == 3) __builtin_nontemporal_store(sum, d);
-        else if (LAB != 1 || sum == (T)12345) *d = sum;
+        const uint32_t slot = g[u] + (uint32_t)__popc(tails & L.under);
+        if (WIDE) {
+          T *d = prod + (int64_t)slot;
+          if (LAB == 3) __builtin_nontemporal_store(sum, d);
+          else if (LAB != 1 || sum == (T)12345) *d = sum;
+        } else {
+          if (LAB == 3) pb_bstore<2>(sum, rprod, (int)(slot * (uint32_t)sizeof(T)));
+          else if (LAB != 1 || sum == (T)12345) pb_bstore<0>(sum, rprod, (int)(slot * (uint32_t)sizeof(T)));
+        }
       }
     }
   };
@@ -1162,16 +1242,19 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
   if (a->pb_fold) {
     const int lab1 = (int)((ctx->opt_ablate >> 2) & 7);
     const dim3 grid1((unsigned)a->pb_nwg);
-#define SAMD_PB1F(LAB)                                                                                                 \
-  hipLaunchKernelGGL((pb_pass1f_kernel<T, 8, LAB>), grid1    , dim3(kPbThreads), 0, ctx->stream,                        \
+#define SAMD_PB1F(LAB, WIDE)                                                                                           \
+  hipLaunchKernelGGL((pb_pass1f_kernel<T, 8, LAB, WIDE>), grid1, dim3(kPbThreads), 0, ctx->stream,                     \
                      (const int64_t *)a->pb_wtab, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,                 \
                      (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w)
+    // products beyond a 32-bit byte offset (or option ablate bit 30, for the tests): stores through 64-bit addresses
+    const bool wide = (a->pb_outputs + 64) * (int64_t)sizeof(T) >= (int64_t)0x7fffffff || ((ctx->opt_ablate >> 30) & 1);
     if (a->pb_nwg <= 0) {}  // nothing stored
-    else if (lab1 == 1) SAMD_PB1F(1);
-    else if (lab1 == 2) SAMD_PB1F(2);
-    else if (lab1 == 3) SAMD_PB1F(3);
-    else if (lab1 == 4) SAMD_PB1F(4);
-    else SAMD_PB1F(0);
+    else if (lab1 == 1) SAMD_PB1F(1, false);
+    else if (lab1 == 2) SAMD_PB1F(2, false);
+    else if (lab1 == 3) SAMD_PB1F(3, false);
+    else if (lab1 == 4) SAMD_PB1F(4, false);
+    else if (wide) SAMD_PB1F(0, true);
+    else SAMD_PB1F(0, false);
 #undef SAMD_PB1F
   }
   else
