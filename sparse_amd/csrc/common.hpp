@@ -299,9 +299,10 @@ struct CsrBody {
   mutable T *cblk_val = nullptr;
   // two-pass copy for gather-bound SpMV on power-law records (spmv_pb.hpp); built lazily
   mutable int pb_state = 0;  // 0 undecided, 1 active, -1 rejected
-  mutable int pb_fold = 0;   // 1: folded layout (pb_col16 bit 15 = first entry of a run, pb_dgroup = first output of every group of 32 entries)
+  mutable int pb_fold = 0;   // 1: folded layout (pb_col16 bit 15 = first entry of a run, pb_dgroup = first output of every group of 32 entries;
+                             // both and pb_val in chunks of 512 entries, a lane's eight entries side by side: pb_pass1f_kernel)
   mutable int64_t pb_outputs = 0;  // products pass 1 writes (pads included)
-  mutable int64_t *pb_wtab = nullptr;  // folded layout: [pb_nwg][3] pass 1's shares (first entry, end, column block)
+  mutable int64_t *pb_wtab = nullptr;  // folded layout: [pb_nwg][3] pass 1's shares (first chunk, end, column block)
   mutable int64_t pb_nwg = 0;
   mutable int64_t pb_np = 0, pb_nb = 0, pb_w = 0, pb_nl = 0;  // panels, column blocks, columns per block, 32-column lines
   mutable int64_t *pb_panel_row = nullptr;   // [np + 1] first row of every panel

@@ -573,42 +573,70 @@ __device__ __forceinline__ T pb_run_sum32(T p, bool all_heads, uint32_t h, const
   return p;
 }
 
-// LAB (kernel lab; results wrong for 1, 2, 4): 1 no store, 2 no LDS gather, 3 non-temporal stores, 4 no run sums
+// ---- pass 1 of the folded layout.
+// Layout read here (pbf_chunk_kernel makes it from the block-major order at the end of the build): every column block
+// is cut into CHUNKS of 512 entries, the block's last chunk filled up with pads; chunk ci is one wavefront's step, its
+// entry u * 64 + l (u = 0 .. 7: the u-th instruction's lane l) stored so that a lane's eight entries are neighbours:
+//   colc[ci * 512 + l * 8 + u]                                    one 16-byte load per lane and chunk
+//   valc[ci * 512 + (u / P) * 64 P + l * P + u % P], P = 16 / sizeof(T)   8 / P 16-byte loads, each one contiguous KiB
+//   outc[ci * 16 + h * 8 + u]                                     first output of half h (lanes 32 h ..) of instruction u
+// Why: with one workgroup per CU (the slice of x takes the LDS) a CU has 16 wavefronts to keep its share of the HBM
+// stream in flight, and a wavefront that asks for a step as 8 + 8 + 8 two- and four-byte loads cannot have more than
+// two steps outstanding (the 6-bit counter of outstanding vector-memory instructions also counts the 8 stores of a
+// step).  Five 16-byte loads per step leave room for a ring of three steps: two are in flight while one is summed.
+typedef unsigned int pb_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPbChunk = 512;  // entries per chunk: 8 per lane
+
+template <class T>
+struct PbChunkRegs {
+  static constexpr int kPer = 16 / (int)sizeof(T), kVecs = 8 / kPer;
+  pb_u32x4 c, v[kVecs], g[2];
+  __device__ __forceinline__ uint32_t col(int u) const { return (u & 1) ? (c[u >> 1] >> 16) & 0x7fffu : c[u >> 1] & 0x7fffu; }
+  __device__ __forceinline__ bool head(int u) const { return (c[u >> 1] & ((u & 1) ? 0x80000000u : 0x8000u)) != 0; }
+  __device__ __forceinline__ uint32_t out(int u) const { return g[u >> 2][u & 3]; }
+  __device__ __forceinline__ T val(int u) const {
+    if constexpr (sizeof(T) == 4) {
+      const uint32_t w = v[u >> 2][u & 3];  // (a bit cast of the element expression itself reads element 0: clang 20)
+      return __builtin_bit_cast(T, w);
+    } else {
+      const uint64_t w = ((uint64_t)v[u >> 1][(u & 1) * 2 + 1] << 32) | v[u >> 1][(u & 1) * 2];
+      return __builtin_bit_cast(T, w);
+    }
+  }
+};
+
+// LAB (kernel lab; results wrong for 1, 2, 4, 5, 6): 1 no store, 2 no LDS gather, 3 non-temporal stores, 4 no run sums,
+// 5 neither stores nor run sums, 6 three whole-wavefront stores per chunk
 // WIDE: the products do not fit a 32-bit byte offset (2^32 / sizeof(T) outputs and more): stores through 64-bit addresses
-template <class T, int U, int LAB, bool WIDE>
+// wtab: per workgroup its first chunk, the chunk behind its last, its column block
+template <class T, int LAB, bool WIDE>
 __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__restrict__ wtab,
-                                                               const uint16_t *__restrict__ col16,
-                                                               const T *__restrict__ pval, const T *__restrict__ xperm,
-                                                               const uint32_t *__restrict__ uout,
+                                                               const uint16_t *__restrict__ colc,
+                                                               const T *__restrict__ valc, const T *__restrict__ xperm,
+                                                               const uint32_t *__restrict__ outc,
                                                                T *__restrict__ prod, int w) {
   __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
-  // the workgroup's share: entries [s, e) of column block b (wtab: the blocks hold very different numbers of entries
-  // when the lines are sorted into them, so the shares are laid out by the host, pb_work_table)
+  typedef PbChunkRegs<T> Regs;
   const int64_t s = wtab[3 * (int64_t)blockIdx.x], e = wtab[3 * (int64_t)blockIdx.x + 1], b = wtab[3 * (int64_t)blockIdx.x + 2];
   {
     constexpr int PER = 16 / (int)sizeof(T);
     const raw16 *src = reinterpret_cast<const raw16 *>(xperm + b * (int64_t)w);
     for (int j = threadIdx.x; j < w / PER; j += kPbThreads) reinterpret_cast<raw16 *>(xs)[j] = src[j];
   }
-  constexpr int64_t kStep = (int64_t)kPbThreads * U;
-  constexpr int kChunk = 64 * U;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const PbLane L(lane);
-  const int off_c = lane * 2, off_v = lane * (int)sizeof(T), off_g = (lane >> 5) * 4;  // the lane offsets of a step's three streams
+  const int off_c = lane * 16, off_g = (lane >> 5) * 32;
   const __amdgpu_buffer_rsrc_t rprod = pb_rsrc(prod);
   __syncthreads();
-  // A wavefront takes 64 U consecutive entries per step: runs are neighbouring lanes.  s, e and every step are
-  // multiples of 32, so lanes 0 and 32 always sit on a forced run start.  The next step's entries are requested
-  // before the current one's runs are summed (the sums are ~25 vector instructions per 64 entries).
-  // (32-bit registers for the 16-bit columns: packed pairs would make each load wait for its neighbour)
-  auto load = [&](int64_t cs, uint32_t (&c)[U], T (&v)[U], uint32_t (&g)[U]) {  // a whole step; cs is the same in every lane
-    const __amdgpu_buffer_rsrc_t rc = pb_rsrc(col16 + cs), rv = pb_rsrc(pval + cs), rg = pb_rsrc(uout + (cs >> 5));
+  auto load = [&](int64_t ci, Regs &r) {  // a whole chunk; ci is the same in every lane
+    const __amdgpu_buffer_rsrc_t rc = pb_rsrc(colc + ci * kPbChunk), rv = pb_rsrc(valc + ci * kPbChunk),
+                                 rg = pb_rsrc(outc + ci * (kPbChunk / 32));
+    r.c = __builtin_amdgcn_raw_buffer_load_b128(rc, off_c, 0, 2);  // aux 2: non-temporal
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      c[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rc, off_c + u * 128, 0, 2);  // aux 2: non-temporal
-      v[u] = pb_bload<2>(rv, off_v + u * 64 * (int)sizeof(T), (const T *)nullptr);
-      g[u] = __builtin_amdgcn_raw_buffer_load_b32(rg, off_g + u * 8, 0, 0);
-    }
+    for (int q = 0; q < Regs::kVecs; q++) r.v[q] = __builtin_amdgcn_raw_buffer_load_b128(rv, off_c + q * 1024, 0, 2);
+    r.g[0] = __builtin_amdgcn_raw_buffer_load_b128(rg, off_g, 0, 0);
+    r.g[1] = __builtin_amdgcn_raw_buffer_load_b128(rg, off_g + 16, 0, 0);
   };
   // The sums are stored where they fall, a group's few at a time: short, unaligned pieces of lines, which the memory
   // system charges per piece rather than per byte (C3, lines sorted into the blocks: 84 M sums = 0.34 GB cost 0.16 ms
@@ -618,66 +646,98 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
   // rows -- (a) across piece boundaries with scalar bookkeeping per half group: 0.687 -> 0.91 ms; (b) only for steps
   // whose 16 groups continue each other (a flag bit per group from the build, one test per step): 0.558 -> 0.584 ms,
   // the LDS round trip costs more than the fuller lines save.
-  auto work = [&](const uint32_t (&c)[U], const T (&v)[U], const uint32_t (&g)[U], int n) {  // n: entries of the step
-    T pr[U];
+  auto work = [&](const Regs &r) {
+    T pr[8];
 #pragma unroll
-    for (int u = 0; u < U; u++) pr[u] = LAB == 2 ? v[u] : (T)(v[u] * xs[c[u] & 0x7fff]);
+    for (int u = 0; u < 8; u++) pr[u] = LAB == 2 ? r.val(u) : (T)(r.val(u) * xs[r.col(u)]);
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const bool ok = u * 64 + lane < n;
-      const unsigned long long heads = __ballot(!ok || (c[u] & 0x8000) != 0);
-      // this lane's half of the mask, picked from two scalars (bit 32 is always set: lane 32 starts a run)
+    for (int u = 0; u < 8; u++) {
+      const unsigned long long heads = __ballot(r.head(u));
+      // this lane's half of the mask, picked from two scalars (bits 0 and 32 are always set: lanes 0 and 32 start a run)
       const uint32_t hlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)heads);
       const uint32_t hhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(heads >> 32));
       const uint32_t h = L.hi ? hhi : hlo;
-      const T sum = LAB == 4 ? pr[u] : pb_run_sum32<T>(pr[u], heads == ~0ull, h, L);
+      const T sum = (LAB == 4 || LAB == 5) ? pr[u] : pb_run_sum32<T>(pr[u], heads == ~0ull, h, L);
       const uint32_t tails = (h >> 1) | 0x80000000u;  // a run ends where the next lane starts one, and at the end of its half
-      if (ok && (tails & L.bit) != 0) {
-        const uint32_t slot = g[u] + (uint32_t)__popc(tails & L.under);
+      if (LAB == 6) {  // lab: three whole-wavefront stores per chunk (about the same bytes as the eight partial ones)
+        if (u < 3) pb_bstore<0>(sum, rprod, (int)((r.out(u) + (uint32_t)L.l5) * (uint32_t)sizeof(T)));
+        else if (sum == (T)12345) pb_bstore<0>(sum, rprod, 0);
+        continue;
+      }
+      if ((tails & L.bit) != 0) {
+        const uint32_t slot = r.out(u) + (uint32_t)__popc(tails & L.under);
         if (WIDE) {
           T *d = prod + (int64_t)slot;
           if (LAB == 3) __builtin_nontemporal_store(sum, d);
-          else if (LAB != 1 || sum == (T)12345) *d = sum;
+          else if ((LAB != 1 && LAB != 5) || sum == (T)12345) *d = sum;
         } else {
           if (LAB == 3) pb_bstore<2>(sum, rprod, (int)(slot * (uint32_t)sizeof(T)));
-          else if (LAB != 1 || sum == (T)12345) pb_bstore<0>(sum, rprod, (int)(slot * (uint32_t)sizeof(T)));
+          else if ((LAB != 1 && LAB != 5) || sum == (T)12345) pb_bstore<0>(sum, rprod, (int)(slot * (uint32_t)sizeof(T)));
         }
       }
     }
   };
-  int64_t cs = s + (int64_t)wave * kChunk;
-  cs = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cs >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)cs);
-  uint32_t ca[U], cb[U], ga[U], gb[U];
-  T va[U], vb[U];
-  // (the next step is requested unconditionally -- when there is none, the current one again, which is in cache:
-  // behind a branch the compiler cannot tell which requests are outstanding where the paths join, and makes the
-  // sums of this step wait for half of the next step's loads)
-  bool more = cs + kChunk <= e;
-  if (more) load(cs, ca, va, ga);
-  while (more) {
-    const int64_t c1 = cs + kStep;
-    const bool more1 = c1 + kChunk <= e;
-    load(more1 ? c1 : cs, cb, vb, gb);
-    work(ca, va, ga, kChunk);
-    cs = c1;
-    if (!more1) break;
-    const int64_t c2 = c1 + kStep;
-    more = c2 + kChunk <= e;
-    load(more ? c2 : c1, ca, va, ga);
-    work(cb, vb, gb, kChunk);
-    cs = c2;
-  }
-  if (cs < e) {  // the range's last, partial step: clamped offsets (never a predicated load, see pb_pass1_kernel)
-    const int n = (int)(e - cs);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int o = u * 64 + lane;
-      const int64_t ic = cs + (o < n ? o : n - 1);
-      ca[u] = (uint32_t)ntload(&col16[ic]);
-      va[u] = ntload(&pval[ic]);
-      ga[u] = uout[ic >> 5];
+  // the wavefront's chunks: s + wave, s + wave + 16, ...  Requests run two chunks ahead; behind the last chunk the
+  // last one is asked for again (it is in cache): behind a branch the compiler cannot tell which requests are
+  // outstanding where the paths join, and makes the sums of this chunk wait for the loads of the next ones.
+  const int64_t first = s + wave;
+  if (first < e) {
+    const int nf = (int)((e - first + kPbWaves - 1) / kPbWaves);
+    const int64_t last = first + (int64_t)(nf - 1) * kPbWaves;
+    auto at = [&](int j) {
+      const int64_t ci = first + (int64_t)j * kPbWaves;
+      return ci < last ? ci : last;
+    };
+    Regs ra, rb, rc;
+    load(at(0), ra);
+    load(at(1), rb);
+    for (int j = 0;;) {
+      load(at(j + 2), rc);
+      work(ra);
+      if (++j >= nf) break;
+      load(at(j + 2), ra);
+      work(rb);
+      if (++j >= nf) break;
+      load(at(j + 2), rb);
+      work(rc);
+      if (++j >= nf) break;
     }
-    work(ca, va, ga, n);
+  }
+}
+
+// The chunked layout pass 1 reads, from the block-major one the build works in (positions = places of the dealt
+// order; bounds[b] = first position of block b).  One wavefront per chunk.  Pads behind a block's end: a run of its
+// own each (bit 15), value 0, outputs in the trash behind the products.
+template <class T>
+__global__ __launch_bounds__(kBlock) void pbf_chunk_kernel(const int64_t *__restrict__ bounds, const int64_t *__restrict__ cbase,
+                                                           int64_t nb, int64_t nchunks, const uint16_t *__restrict__ col16,
+                                                           const T *__restrict__ pval, const uint32_t *__restrict__ uout,
+                                                           uint32_t trash, uint16_t *__restrict__ colc, T *__restrict__ valc,
+                                                           uint32_t *__restrict__ outc) {
+  constexpr int kPer = 16 / (int)sizeof(T);
+  const int64_t ci = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (ci >= nchunks) return;
+  int64_t lo = 0, hi = nb;  // largest b with cbase[b] <= ci (behind empty blocks: the one that holds the chunk)
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (cbase[mid] <= ci) lo = mid; else hi = mid;
+  }
+  const int64_t ls = bounds[lo] + (ci - cbase[lo]) * kPbChunk;
+  const int64_t left = bounds[lo + 1] - ls;
+  const int n = left < kPbChunk ? (int)left : kPbChunk;
+  uint16_t *cd = colc + ci * kPbChunk + lane * 8;
+  T *vd = valc + ci * kPbChunk;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int o = u * 64 + lane;
+    const bool ok = o < n;
+    cd[u] = ok ? col16[ls + o] : (uint16_t)0x8000;
+    vd[(u / kPer) * (64 * kPer) + lane * kPer + u % kPer] = ok ? pval[ls + o] : (T)0;
+  }
+  if (lane < kPbChunk / 32) {
+    const int k = 2 * (lane & 7) + (lane >> 3);  // group of instruction u = lane & 7, half lane >> 3
+    outc[ci * (kPbChunk / 32) + lane] = k * 32 < n ? uout[(ls >> 5) + k] : trash;
   }
 }
 
@@ -961,46 +1021,60 @@ int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, co
   hipLaunchKernelGGL(pbf_bounds_kernel, dim3((unsigned)cdiv(nb + 1 + np + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                      (const int64_t *)sbase.p, (const int64_t *)spos.p, (const int64_t *)poff.p, np, nb, bounds.p);
   SAMD_LAUNCH_CHECK(ctx);
-  SAMD_TRY(prod.get(ototal));
-  SAMD_HIP(ctx, hipMemsetAsync(prod.p, 0, sizeof(T) * (size_t)ototal, ctx->stream));  // output pads are read by pass 2 (into the trash slots)
-  // ---- pass 1's shares: about four workgroups per CU, every block cut into shares of whole steps in proportion to
-  // its entries (at least one)
+  SAMD_TRY(prod.get(ototal + 64));  // behind the outputs: the trash the pads of the chunked layout write to
+  SAMD_HIP(ctx, hipMemsetAsync(prod.p, 0, sizeof(T) * (size_t)(ototal + 64), ctx->stream));  // output pads are read by pass 2 (into the trash slots)
+  // ---- the chunked layout pass 1 reads, and pass 1's shares: about four workgroups per CU, every block cut into
+  // shares of whole chunks in proportion to its entries (at least one)
   std::vector<int64_t> hb((size_t)nb + 1);
   SAMD_HIP(ctx, hipMemcpyAsync(hb.data(), bounds.p, sizeof(int64_t) * (size_t)(nb + 1), hipMemcpyDeviceToHost, ctx->stream));
-  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // also orders the temporaries' release after their use
-  std::vector<int64_t> wt;
+  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<int64_t> wt, cb((size_t)nb + 1);
+  cb[0] = 0;
+  for (int64_t b = 0; b < nb; b++) cb[(size_t)b + 1] = cb[(size_t)b] + cdiv(hb[(size_t)b + 1] - hb[(size_t)b], kPbChunk);
+  const int64_t nchunks = cb[(size_t)nb];
   {
-    constexpr int64_t kStep = (int64_t)kPbThreads * 8;  // pb_pass1f_kernel<T, 8>
     const int64_t target = (int64_t)ctx->num_cu * (ctx->opt_spmv_pb_shares > 0 ? ctx->opt_spmv_pb_shares : 4);
-    const int64_t total = hb[(size_t)nb] - hb[0] > 0 ? hb[(size_t)nb] - hb[0] : 1;
+    const int64_t total = nchunks > 0 ? nchunks : 1;
     for (int64_t b = 0; b < nb; b++) {
-      const int64_t s0 = hb[(size_t)b], e0 = hb[(size_t)b + 1];
-      if (e0 <= s0) continue;
-      const int64_t steps = cdiv(e0 - s0, kStep);
-      int64_t shares = ((e0 - s0) * target + total / 2) / total;
+      const int64_t c0 = cb[(size_t)b], c1 = cb[(size_t)b + 1];
+      if (c1 <= c0) continue;
+      int64_t shares = ((c1 - c0) * target + total / 2) / total;
       if (shares < 1) shares = 1;
-      if (shares > steps) shares = steps;
-      const int64_t per = cdiv(steps, shares) * kStep;
-      for (int64_t s = s0; s < e0; s += per) {
-        wt.push_back(s);
-        wt.push_back(s + per < e0 ? s + per : e0);
+      if (shares > c1 - c0) shares = c1 - c0;
+      const int64_t per = cdiv(c1 - c0, shares);
+      for (int64_t c = c0; c < c1; c += per) {
+        wt.push_back(c);
+        wt.push_back(c + per < c1 ? c + per : c1);
         wt.push_back(b);
       }
     }
   }
-  Tmp<int64_t> wtab(ctx);
+  Tmp<int64_t> wtab(ctx), cbase(ctx);
+  Tmp<uint16_t> colc(ctx);
+  Tmp<T> valc(ctx);
+  Tmp<uint32_t> outc(ctx);
   SAMD_TRY(wtab.get((int64_t)wt.size()));
-  if (!wt.empty()) {
+  SAMD_TRY(cbase.get(nb + 1));
+  SAMD_TRY(colc.get(nchunks * kPbChunk));
+  SAMD_TRY(valc.get(nchunks * kPbChunk));
+  SAMD_TRY(outc.get(nchunks * (kPbChunk / 32)));
+  SAMD_HIP(ctx, hipMemcpyAsync(cbase.p, cb.data(), sizeof(int64_t) * cb.size(), hipMemcpyHostToDevice, ctx->stream));
+  if (!wt.empty())
     SAMD_HIP(ctx, hipMemcpyAsync(wtab.p, wt.data(), sizeof(int64_t) * wt.size(), hipMemcpyHostToDevice, ctx->stream));
-    SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // wt is host memory that goes away
+  if (nchunks > 0) {
+    hipLaunchKernelGGL((pbf_chunk_kernel<T>), dim3((unsigned)cdiv(nchunks, kBlock / 64)), dim3(kBlock), 0, ctx->stream,
+                       (const int64_t *)bounds.p, (const int64_t *)cbase.p, nb, nchunks, (const uint16_t *)col16.p,
+                       (const T *)pval.p, (const uint32_t *)uout.p, (uint32_t)ototal, colc.p, valc.p, outc.p);
+    SAMD_LAUNCH_CHECK(ctx);
   }
+  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // wt and cb are host memory that goes away; the temporaries are released after their use
   a->pb_wtab = wtab.release();
   a->pb_nwg = (int64_t)wt.size() / 3;
   a->pb_piece_ptr = bounds.release();
-  a->pb_dgroup = uout.release();
-  a->pb_col16 = col16.release();
+  a->pb_dgroup = outc.release();
+  a->pb_col16 = colc.release();
   a->pb_row16 = row16.release();
-  a->pb_val = pval.release();
+  a->pb_val = valc.release();
   a->pb_prod = prod.release();
   a->pb_fold = 1;
   a->pb_outputs = ototal;
@@ -1243,7 +1317,7 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
     const int lab1 = (int)((ctx->opt_ablate >> 2) & 7);
     const dim3 grid1((unsigned)a->pb_nwg);
 #define SAMD_PB1F(LAB, WIDE)                                                                                           \
-  hipLaunchKernelGGL((pb_pass1f_kernel<T, 8, LAB, WIDE>), grid1, dim3(kPbThreads), 0, ctx->stream,                     \
+  hipLaunchKernelGGL((pb_pass1f_kernel<T, LAB, WIDE>), grid1, dim3(kPbThreads), 0, ctx->stream,                        \
                      (const int64_t *)a->pb_wtab, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,                 \
                      (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w)
     // products beyond a 32-bit byte offset (or option ablate bit 30, for the tests): stores through 64-bit addresses
@@ -1253,6 +1327,8 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
     else if (lab1 == 2) SAMD_PB1F(2, false);
     else if (lab1 == 3) SAMD_PB1F(3, false);
     else if (lab1 == 4) SAMD_PB1F(4, false);
+    else if (lab1 == 5) SAMD_PB1F(5, false);
+    else if (lab1 == 6) SAMD_PB1F(6, false);
     else if (wide) SAMD_PB1F(0, true);
     else SAMD_PB1F(0, false);
 #undef SAMD_PB1F
