@@ -46,7 +46,7 @@ def main():
     import torch
     from sparse_amd import Context, mk_compressed, synth
     dev = torch.device("cuda", 0)
-    ctx = Context(0)
+    ctx = Context(0, logging=bool(os.environ.get("SAMD_LOG")))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.algo:
         ctx.set_option("spmv_algo", args.algo)
