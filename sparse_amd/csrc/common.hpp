@@ -125,6 +125,7 @@ struct futhark_context {
   int64_t opt_spmv_pb_fold = 0;  // two-pass SpMV, products of one row inside one piece summed in pass 1: 0 when it shortens the product stream by >= 15 %, 1 always, -1 never
   int64_t opt_spmv_pb_deal = 0;    // lines into column blocks: 0 sorted by popularity for skewed records (with the folded layout), dealt round otherwise; 1 always sorted; -1 always dealt
   int64_t opt_spmv_pb_shares = 0;  // lab: folded layout, pass 1's workgroups per CU (0 = 4)
+  int64_t opt_spmv_pb_oround = 0;  // lab: folded layout, alignment of a piece's outputs in products (0 = kPbOutRound)
   int64_t last_pb_fold = 0;      // 1 if the last two-pass product ran on a folded layout; last_pb_outputs: products it wrote (pads included)
   int64_t last_pb_outputs = 0;
   int64_t opt_sort_indirect = 0;  // lab: 1 = assembly sorts 8-byte values by 4-byte source index and gathers them at the end
@@ -301,7 +302,7 @@ struct CsrBody {
   mutable int pb_fold = 0;   // 1: folded layout (pb_col16 bit 15 = first entry of a run, pb_dgroup = first output of every group of 32 entries;
                              // both and pb_val in chunks of 512 entries, a lane's eight entries side by side: pb_pass1f_kernel)
   mutable int64_t pb_outputs = 0;  // products pass 1 writes (pads included)
-  mutable int64_t *pb_wtab = nullptr;  // folded layout: [16 pb_nwg + 1][2] pass 1's wavefront ranges (first step, column block)
+  mutable int64_t *pb_wtab = nullptr;  // folded layout: [pb_nwg][3] pass 1's shares (first chunk, end, column block)
   mutable int64_t pb_nwg = 0;
   mutable int64_t pb_np = 0, pb_nb = 0, pb_w = 0, pb_nl = 0;  // panels, column blocks, columns per block, 32-column lines
   mutable int64_t *pb_panel_row = nullptr;   // [np + 1] first row of every panel

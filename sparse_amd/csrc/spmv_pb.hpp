@@ -58,7 +58,9 @@ constexpr int64_t kPbMinBytes = 16 << 20;            // x at least this large (R
                                                     // scale 20 0.21 / 0.15, 21 0.264 / 0.259, 22 0.47 / 0.51, 23 0.81 / 1.01, 24 1.62 / 2.08)
 constexpr int kPbFoldRows = 64;                     // a panel of fewer rows than this keeps its entries sorted by row: pass 2 folds runs
 constexpr int kPbFoldFlag = 0x8000;                 // row16 bit that says so
-constexpr int kPbRunCap = 32;                       // folded layout: a row's entries inside a piece are cut into runs of at most this many
+constexpr int kPbRunCap = 32;                       // folded layout: a run is cut at every multiple of this many positions (C3, 16 -- runs inside one DPP row, one scan step fewer: pass 1 the same 0.557 ms, 7 % more products, pass 2 0.160 -> 0.184)
+constexpr int kPbOutRound = 8;                      // folded layout: a piece's outputs start at a multiple of this many products (C3, round 3, chunked layout, 32 / 16 / 8: pass 1 0.504 / 0.501 / 0.498 ms, pass 2 0.158 / 0.155 / 0.1545, 95.7 / 89.0 / 86.1 M products; round 2's kernel liked 32: 1 / 8 / 16 / 32 gave pass 1 0.714 / 0.707 / 0.694 / 0.687)
+constexpr int64_t kPbPanelEntriesFolded = 512 << 10; // the same for the folded layout, whose pass 2 sees a third of the entries (C3, 256 K / 512 K / 1 M: pass 1 0.521 / 0.504 / 0.501 ms, pass 2 0.160 / 0.162 / 0.165, 100.6 / 95.7 / 93.7 M products)
 constexpr int64_t kPbMinPiece = 128;               // auto mode: mean entries per piece below this -> not worth it
 
 // Popularity of the 32-column lines from every stride-th entry: the ranking only has to deal the lines to the
@@ -418,52 +420,329 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__r
 // ------------------------------------------------------------------------------------------------ folded layout
 // On a power-law matrix a heavy row has many entries in one column block: their products belong to one element of
 // y, and pass 1 can add them up before anything is written.  C3: a row of 1300 entries meets each of the 512 blocks
-// 2.5 times, the 13 000 heaviest rows (28 % of the entries) 8 times and more; with the lines sorted into the blocks
-// by popularity 72 % of the products disappear.
-// Layout (round 3, third form).  A piece's entries are grouped in RUNS: a row's n entries inside the piece are cut
-// into runs of 32 and then along the bits of what is left (13 = 8 + 4 + 1), so a run is 1, 2, 4, 8, 16 or 32 entries
-// long.  The runs of a piece are sorted by length: a CLASS = the runs of one piece with one length L, its entries
-// stored run after run, its sums run after run in the panel-major output stream.  Pass 1 walks a list of STEPS of
-// up to 256 entries of one class: lane l loads its four entries as one 8-byte and one 16-byte piece, multiplies,
-// adds up what belongs to one run -- 4 / L runs inside the lane for L <= 4, L / 4 neighbouring lanes by DPP moves
-// above that -- and the step's sums leave as one contiguous store.  Regular by construction: no run boundaries to
-// find, no step that depends on another, any step range can be any wavefront's.
-// What led here (C3, pass 1 alone): runs as neighbouring lanes of one instruction, summed by segmented scans, a
-// run's last lane storing: 0.53 ms, bound by its 36 vector instructions per 64 entries and by stores of a third of a
-// wavefront; lane = run with the entries as jagged diagonals (64 entries per step, two 2- and 4-byte loads): 0.58 ms,
-// bound by the number of vector-memory instructions (a CU retires one per ~16 cycles whatever its width).
-// Among the runs of a class the order is the bank-pair deal of the plain layout: pass 2's LDS atomics of one
-// instruction then meet each bank pair about once.
-// desc[step] = {first entry, first output, lanes | class << 8, -}; class c: L = 32 >> c.
-constexpr int kPbClasses = 6;
-constexpr int kPbStepEntries = 256;  // 64 lanes x 4 entries
-
-struct PbRunHeadIn {  // 1 where sorted entry i starts a row's entries inside a piece
-  const uint32_t *keys;
-  const uint16_t *rr;
-  __device__ __forceinline__ uint32_t operator()(int64_t i) const {
-    return (i == 0 || (keys[i] >> 5) != (keys[i - 1] >> 5) || rr[i] != rr[i - 1]) ? 1u : 0u;
+// 2.5 times, the 13 000 heaviest rows (28 % of the entries) 8 times and more; the product stream shrinks to about
+// half, which takes 10 bytes per dropped product off the 16 the two passes move per entry.
+// Layout: a piece's entries are grouped in RUNS (one row each), a run's entries are neighbours in the block-major
+// stream, bit 15 of col16 marks a run's first entry and every position that is a multiple of 32 starts a new run
+// (so a run never leaves the 32 lanes that hold its group).  Pass 1 forms the products, adds each run up inside the
+// wavefront (segmented scan over DPP moves, skipped when the instruction holds no run longer than one entry) and the
+// last lane of a run stores the sum at pb_dgroup[group] + (runs before it in the group): the outputs of a piece
+// are contiguous in the panel-major stream, in the order of its runs.  That order is the bank-pair deal of the
+// plain layout applied to runs, so pass 2 (the same kernel, nothing to fold any more) still sees each bank pair
+// about once per instruction.  Pads: the first pad of a piece starts a run whose row is the trash slot.
+template <int CTRL, int ROWMASK, class T>
+__device__ __forceinline__ T pb_dpp0(T v) {  // lanes without a source (or outside ROWMASK) read 0
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+  } else {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, ROWMASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, ROWMASK, 0xf, false);
+    return __builtin_bit_cast(T, ((uint64_t)hi << 32) | lo);
   }
+}
+
+// Per-lane constants of the run arithmetic.  A run never leaves its 32-lane half (positions that are multiples of 32
+// start a run), so every lane works on its half's 32 bits of the wavefront's masks.
+struct PbLane {
+  int lane, l5;
+  bool hi;
+  uint32_t upto, bit, under;  // bits 0..l5, bit l5, bits 0..l5-1
+  __device__ __forceinline__ explicit PbLane(int ln) : lane(ln), l5(ln & 31), hi(ln >= 32) {
+    bit = 1u << l5;
+    under = bit - 1u;
+    upto = under | bit;
+  }
+  __device__ __forceinline__ uint32_t half(unsigned long long m) const { return hi ? (uint32_t)(m >> 32) : (uint32_t)m; }
 };
 
-struct PbSubHeadIn {  // 1 where a run starts: n entries of a row = runs of 32, then the bits of n mod 32 from the top
-  const uint32_t *id0;         // inclusive sums of PbRunHeadIn
-  const uint32_t *row_start;   // first entry of every row-in-piece, then nnz
-  __device__ __forceinline__ uint32_t operator()(int64_t i) const {
-    const uint32_t id = id0[i] - 1, s = row_start[id], n = row_start[id + 1] - s, t = (uint32_t)i - s;
-    const uint32_t full = n & ~(uint32_t)(kPbRunCap - 1);
-    if (t < full) return (t & (kPbRunCap - 1)) == 0 ? 1u : 0u;
-    uint32_t pos = full;
-#pragma unroll
-    for (uint32_t bit = kPbRunCap / 2; bit >= 1; bit >>= 1)
-      if (n & bit) {
-        if (t < pos + bit) return t == pos ? 1u : 0u;
-        pos += bit;
+// heads: lanes that start a run (lanes 0 and 32 among them).  Returns in a run's last lane the sum of the run.
+template <class T>
+__device__ __forceinline__ T pb_run_sum(T p, unsigned long long heads, const PbLane &L) {
+  if (heads == ~0ull) return p;  // every run is one entry (the thin part of the matrix)
+  const int dist = L.l5 - 31 + __builtin_clz(L.half(heads) & L.upto);  // distance to the run's first lane
+  {
+    const T t = pb_dpp0<0x111, 0xf>(p);  // row_shr:1
+    if (dist >= 1) p = (T)(p + t);
+  }
+  if (__ballot(dist >= 2) != 0ull) {
+    {
+      const T t = pb_dpp0<0x112, 0xf>(p);
+      if (dist >= 2) p = (T)(p + t);
+    }
+    if (__ballot(dist >= 4) != 0ull) {
+      {
+        const T t = pb_dpp0<0x114, 0xf>(p);
+        if (dist >= 4) p = (T)(p + t);
       }
-    return 1u;  // not reached
+      {
+        const T t = pb_dpp0<0x118, 0xf>(p);
+        if (dist >= 8) p = (T)(p + t);
+      }
+    }
+  }
+  // a run that began in the 16 lanes before this row: lane 15 of that row holds its part there
+  if (kPbRunCap > 16) {
+    const T t = pb_dpp0<0x142, 0xa>(p);  // row_bcast:15 into rows 1 and 3
+    if (dist > (L.lane & 15)) p = (T)(p + t);
+  }
+  return p;
+}
+
+__device__ __forceinline__ int pb_rank_in_half(unsigned long long mask, int lane) {  // set bits below the lane inside its 32-lane half
+  const PbLane L(lane);
+  return __popc(L.half(mask) & L.under);
+}
+
+template <class P>
+__device__ __forceinline__ P *pb_uniform_ptr(P *p) {  // p is the same in every lane: keep it in scalar registers
+  const uint64_t u = (uint64_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  typedef __attribute__((address_space(1))) P G;  // global memory: an integer cast alone would leave a generic (flat) pointer
+  return (P *)(G *)(((uint64_t)hi << 32) | lo);
+}
+
+// ---- buffer addressing for pass 1's streams.  A global load or store through a 64-bit vector address costs a
+// 64-bit vector add per access (v_lshl_add_u64, not a full-rate instruction), and pass 1 is bound by vector issue:
+// 36 vector instructions per 64 entries, 10 of them address arithmetic.  Buffer instructions take a scalar
+// descriptor (the base moves with the step: scalar adds, which issue beside the vector ones), one 32-bit lane offset
+// that never changes, and an immediate: no vector instruction per load at all, three (and, bcnt + base, shift) per
+// store.  The descriptors are raw (stride 0) with the range check out of the way: every offset is in range by
+// construction of the layout.
+typedef unsigned int pb_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kPbRsrcFlags = 0x00020000;  // gfx9 raw buffer, 32-bit data format
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pb_rsrc(const void *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffffe, kPbRsrcFlags);
+}
+template <int AUX>
+__device__ __forceinline__ float pb_bload(__amdgpu_buffer_rsrc_t r, int off, const float *) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ int32_t pb_bload(__amdgpu_buffer_rsrc_t r, int off, const int32_t *) {
+  return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ double pb_bload(__amdgpu_buffer_rsrc_t r, int off, const double *) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void pb_bstore(float v, __amdgpu_buffer_rsrc_t r, int off) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void pb_bstore(int32_t v, __amdgpu_buffer_rsrc_t r, int off) {
+  __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, r, off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void pb_bstore(double v, __amdgpu_buffer_rsrc_t r, int off) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pb_u32x2, v), r, off, 0, AUX);
+}
+
+// the run sums of one instruction's 64 products; h: this lane's half of the heads mask.  As pb_run_sum, on 32-bit
+// masks only (a 64-bit vector shift per use is what the compiler makes of `lane < 32 ? lo : hi` otherwise).
+template <class T>
+__device__ __forceinline__ T pb_run_sum32(T p, bool all_heads, uint32_t h, const PbLane &L) {
+  if (all_heads) return p;  // every run is one entry (the thin part of the matrix)
+  const int dist = L.l5 - 31 + __builtin_clz(h & L.upto);  // distance to the run's first lane
+  {
+    const T t = pb_dpp0<0x111, 0xf>(p);  // row_shr:1
+    if (dist >= 1) p = (T)(p + t);
+  }
+  if (__ballot(dist >= 2) != 0ull) {
+    {
+      const T t = pb_dpp0<0x112, 0xf>(p);
+      if (dist >= 2) p = (T)(p + t);
+    }
+    if (__ballot(dist >= 4) != 0ull) {
+      {
+        const T t = pb_dpp0<0x114, 0xf>(p);
+        if (dist >= 4) p = (T)(p + t);
+      }
+      {
+        const T t = pb_dpp0<0x118, 0xf>(p);
+        if (dist >= 8) p = (T)(p + t);
+      }
+    }
+  }
+  if (kPbRunCap > 16) {  // a run that began in the 16 lanes before this row: lane 15 of that row holds its part there
+    const T t = pb_dpp0<0x142, 0xa>(p);  // row_bcast:15 into rows 1 and 3
+    if (dist > (L.lane & 15)) p = (T)(p + t);
+  }
+  return p;
+}
+
+// ---- pass 1 of the folded layout.
+// Layout read here (pbf_chunk_kernel makes it from the block-major order at the end of the build): every column block
+// is cut into CHUNKS of 512 entries, the block's last chunk filled up with pads; chunk ci is one wavefront's step, its
+// entry u * 64 + l (u = 0 .. 7: the u-th instruction's lane l) stored so that a lane's eight entries are neighbours:
+//   colc[ci * 512 + l * 8 + u]                                    one 16-byte load per lane and chunk
+//   valc[ci * 512 + (u / P) * 64 P + l * P + u % P], P = 16 / sizeof(T)   8 / P 16-byte loads, each one contiguous KiB
+//   outc[ci * 16 + h * 8 + u]                                     first output of half h (lanes 32 h ..) of instruction u
+// Why: with one workgroup per CU (the slice of x takes the LDS) a CU has 16 wavefronts to keep its share of the HBM
+// stream in flight, and a wavefront that asks for a step as 8 + 8 + 8 two- and four-byte loads cannot have more than
+// two steps outstanding (the 6-bit counter of outstanding vector-memory instructions also counts the 8 stores of a
+// step).  Five 16-byte loads per step leave room for a ring of three steps: two are in flight while one is summed.
+typedef unsigned int pb_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPbChunk = 512;  // entries per chunk: 8 per lane
+
+template <class T>
+struct PbChunkRegs {
+  static constexpr int kPer = 16 / (int)sizeof(T), kVecs = 8 / kPer;
+  pb_u32x4 c, v[kVecs], g[2];
+  __device__ __forceinline__ uint32_t col(int u) const { return (u & 1) ? (c[u >> 1] >> 16) & 0x7fffu : c[u >> 1] & 0x7fffu; }
+  __device__ __forceinline__ bool head(int u) const { return (c[u >> 1] & ((u & 1) ? 0x80000000u : 0x8000u)) != 0; }
+  __device__ __forceinline__ uint32_t out(int u) const { return g[u >> 2][u & 3]; }
+  __device__ __forceinline__ T val(int u) const {
+    if constexpr (sizeof(T) == 4) {
+      const uint32_t w = v[u >> 2][u & 3];  // (a bit cast of the element expression itself reads element 0: clang 20)
+      return __builtin_bit_cast(T, w);
+    } else {
+      const uint64_t w = ((uint64_t)v[u >> 1][(u & 1) * 2 + 1] << 32) | v[u >> 1][(u & 1) * 2];
+      return __builtin_bit_cast(T, w);
+    }
   }
 };
 
+// LAB (kernel lab; results wrong for 1, 2, 4, 5, 6): 1 no store, 2 no LDS gather, 3 non-temporal stores, 4 no run sums,
+// 5 neither stores nor run sums, 6 three whole-wavefront stores per chunk
+// WIDE: the products do not fit a 32-bit byte offset (2^32 / sizeof(T) outputs and more): stores through 64-bit addresses
+// wtab: per workgroup its first chunk, the chunk behind its last, its column block
+template <class T, int LAB, bool WIDE>
+__global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__restrict__ wtab,
+                                                               const uint16_t *__restrict__ colc,
+                                                               const T *__restrict__ valc, const T *__restrict__ xperm,
+                                                               const uint32_t *__restrict__ outc,
+                                                               T *__restrict__ prod, int w) {
+  __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
+  typedef PbChunkRegs<T> Regs;
+  const int64_t s = wtab[3 * (int64_t)blockIdx.x], e = wtab[3 * (int64_t)blockIdx.x + 1], b = wtab[3 * (int64_t)blockIdx.x + 2];
+  {
+    constexpr int PER = 16 / (int)sizeof(T);
+    const raw16 *src = reinterpret_cast<const raw16 *>(xperm + b * (int64_t)w);
+    for (int j = threadIdx.x; j < w / PER; j += kPbThreads) reinterpret_cast<raw16 *>(xs)[j] = src[j];
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const PbLane L(lane);
+  const int off_c = lane * 16, off_g = (lane >> 5) * 32;
+  const __amdgpu_buffer_rsrc_t rprod = pb_rsrc(prod);
+  __syncthreads();
+  auto load = [&](int64_t ci, Regs &r) {  // a whole chunk; ci is the same in every lane
+    const __amdgpu_buffer_rsrc_t rc = pb_rsrc(colc + ci * kPbChunk), rv = pb_rsrc(valc + ci * kPbChunk),
+                                 rg = pb_rsrc(outc + ci * (kPbChunk / 32));
+    r.c = __builtin_amdgcn_raw_buffer_load_b128(rc, off_c, 0, 2);  // aux 2: non-temporal
+#pragma unroll
+    for (int q = 0; q < Regs::kVecs; q++) r.v[q] = __builtin_amdgcn_raw_buffer_load_b128(rv, off_c + q * 1024, 0, 2);
+    r.g[0] = __builtin_amdgcn_raw_buffer_load_b128(rg, off_g, 0, 0);
+    r.g[1] = __builtin_amdgcn_raw_buffer_load_b128(rg, off_g + 16, 0, 0);
+  };
+  // The sums are stored where they fall, a group's few at a time: short, unaligned pieces of lines, which the memory
+  // system charges per piece rather than per byte (C3, lines sorted into the blocks: 84 M sums = 0.34 GB cost 0.16 ms
+  // where the 2 GB of entries stream in 0.40).  Plain stores, so that L2 can put the pieces of a line together
+  // (non-temporal: pass 1 0.615 instead of 0.558 ms; the next kernel then pays 0.02 ms for the write-backs).
+  // Tried twice and dropped: collecting the sums in a per-wavefront row of LDS and writing whole aligned 256-byte
+  // rows -- (a) across piece boundaries with scalar bookkeeping per half group: 0.687 -> 0.91 ms; (b) only for steps
+  // whose 16 groups continue each other (a flag bit per group from the build, one test per step): 0.558 -> 0.584 ms,
+  // the LDS round trip costs more than the fuller lines save.
+  auto work = [&](const Regs &r) {
+    T pr[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) pr[u] = LAB == 2 ? r.val(u) : (T)(r.val(u) * xs[r.col(u)]);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const unsigned long long heads = __ballot(r.head(u));
+      // this lane's half of the mask, picked from two scalars (bits 0 and 32 are always set: lanes 0 and 32 start a run)
+      const uint32_t hlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)heads);
+      const uint32_t hhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(heads >> 32));
+      const uint32_t h = L.hi ? hhi : hlo;
+      const T sum = (LAB == 4 || LAB == 5) ? pr[u] : pb_run_sum32<T>(pr[u], heads == ~0ull, h, L);
+      const uint32_t tails = (h >> 1) | 0x80000000u;  // a run ends where the next lane starts one, and at the end of its half
+      if (LAB == 6) {  // lab: three whole-wavefront stores per chunk (about the same bytes as the eight partial ones)
+        if (u < 3) pb_bstore<0>(sum, rprod, (int)((r.out(u) + (uint32_t)L.l5) * (uint32_t)sizeof(T)));
+        else if (sum == (T)12345) pb_bstore<0>(sum, rprod, 0);
+        continue;
+      }
+      if ((tails & L.bit) != 0) {
+        const uint32_t slot = r.out(u) + (uint32_t)__popc(tails & L.under);
+        if (WIDE) {
+          T *d = prod + (int64_t)slot;
+          if (LAB == 3) __builtin_nontemporal_store(sum, d);
+          else if ((LAB != 1 && LAB != 5) || sum == (T)12345) *d = sum;
+        } else {
+          if (LAB == 3) pb_bstore<2>(sum, rprod, (int)(slot * (uint32_t)sizeof(T)));
+          else if ((LAB != 1 && LAB != 5) || sum == (T)12345) pb_bstore<0>(sum, rprod, (int)(slot * (uint32_t)sizeof(T)));
+        }
+      }
+    }
+  };
+  // the wavefront's chunks: s + wave, s + wave + 16, ...  Requests run two chunks ahead; behind the last chunk the
+  // last one is asked for again (it is in cache): behind a branch the compiler cannot tell which requests are
+  // outstanding where the paths join, and makes the sums of this chunk wait for the loads of the next ones.
+  const int64_t first = s + wave;
+  if (first < e) {
+    const int nf = (int)((e - first + kPbWaves - 1) / kPbWaves);
+    const int64_t last = first + (int64_t)(nf - 1) * kPbWaves;
+    auto at = [&](int j) {
+      const int64_t ci = first + (int64_t)j * kPbWaves;
+      return ci < last ? ci : last;
+    };
+    Regs ra, rb, rc;
+    load(at(0), ra);
+    load(at(1), rb);
+    for (int j = 0;;) {
+      load(at(j + 2), rc);
+      work(ra);
+      if (++j >= nf) break;
+      load(at(j + 2), ra);
+      work(rb);
+      if (++j >= nf) break;
+      load(at(j + 2), rb);
+      work(rc);
+      if (++j >= nf) break;
+    }
+  }
+}
+
+// The chunked layout pass 1 reads, from the block-major one the build works in (positions = places of the dealt
+// order; bounds[b] = first position of block b).  One wavefront per chunk.  Pads behind a block's end: a run of its
+// own each (bit 15), value 0, outputs in the trash behind the products.
+template <class T>
+__global__ __launch_bounds__(kBlock) void pbf_chunk_kernel(const int64_t *__restrict__ bounds, const int64_t *__restrict__ cbase,
+                                                           int64_t nb, int64_t nchunks, const uint16_t *__restrict__ col16,
+                                                           const T *__restrict__ pval, const uint32_t *__restrict__ uout,
+                                                           uint32_t trash, uint16_t *__restrict__ colc, T *__restrict__ valc,
+                                                           uint32_t *__restrict__ outc) {
+  constexpr int kPer = 16 / (int)sizeof(T);
+  const int64_t ci = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (ci >= nchunks) return;
+  int64_t lo = 0, hi = nb;  // largest b with cbase[b] <= ci (behind empty blocks: the one that holds the chunk)
+  while (hi - lo > 1) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (cbase[mid] <= ci) lo = mid; else hi = mid;
+  }
+  const int64_t ls = bounds[lo] + (ci - cbase[lo]) * kPbChunk;
+  const int64_t left = bounds[lo + 1] - ls;
+  const int n = left < kPbChunk ? (int)left : kPbChunk;
+  uint16_t *cd = colc + ci * kPbChunk + lane * 8;
+  T *vd = valc + ci * kPbChunk;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int o = u * 64 + lane;
+    const bool ok = o < n;
+    cd[u] = ok ? col16[ls + o] : (uint16_t)0x8000;
+    vd[(u / kPer) * (64 * kPer) + lane * kPer + u % kPer] = ok ? pval[ls + o] : (T)0;
+  }
+  if (lane < kPbChunk / 32) {
+    const int k = 2 * (lane & 7) + (lane >> 3);  // group of instruction u = lane & 7, half lane >> 3
+    outc[ci * (kPbChunk / 32) + lane] = k * 32 < n ? uout[(ls >> 5) + k] : trash;
+  }
+}
+
+// ---- building the folded layout (once per record) from the entries sorted by (piece, row mod 32, row, column)
 __global__ __launch_bounds__(kBlock) void pbf_rows_kernel(const int64_t *__restrict__ row_ptr, int64_t nnz,
                                                           const int64_t *__restrict__ tile_lb, int64_t tile,
                                                           const int64_t *__restrict__ panel_row, int64_t np,
@@ -476,484 +755,371 @@ __global__ __launch_bounds__(kBlock) void pbf_rows_kernel(const int64_t *__restr
   rr[i] = (uint16_t)(find_row(row_ptr, tile_lb, tile, src) - panel_row[p]);
 }
 
-// start[j] = position of the j-th head, start[heads] = n (hscan: inclusive sums of the head flags)
-template <class HeadIn>
-__global__ __launch_bounds__(kBlock) void pbf_starts_kernel(HeadIn head, const uint32_t *__restrict__ hscan, int64_t n,
-                                                            uint32_t *__restrict__ start) {
+struct PbRunHeadIn {  // 1 where sorted entry i starts a run: first of its piece or another row than its predecessor
+  const uint32_t *keys;
+  const uint16_t *rr;
+  __device__ __forceinline__ uint32_t operator()(int64_t i) const {
+    return (i == 0 || (keys[i] >> 5) != (keys[i - 1] >> 5) || rr[i] != rr[i - 1]) ? 1u : 0u;
+  }
+};
+
+struct PbU32AsI64In {
+  const uint32_t *p;
+  __device__ __forceinline__ int64_t operator()(int64_t i) const { return (int64_t)p[i]; }
+};
+
+// run_start[j] = sorted position of run j's first entry, run_start[runs] = nnz
+__global__ __launch_bounds__(kBlock) void pbf_runstart_kernel(PbRunHeadIn head, const uint32_t *__restrict__ hscan,
+                                                              int64_t nnz, uint32_t *__restrict__ run_start) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  if (head(i)) start[hscan[i] - 1] = (uint32_t)i;
-  if (i == n - 1) start[hscan[i]] = (uint32_t)n;
+  if (i >= nnz) return;
+  if (head(i)) run_start[hscan[i] - 1] = (uint32_t)i;
+  if (i == nnz - 1) run_start[hscan[i]] = (uint32_t)nnz;
 }
 
-// sort key of run j: its piece, then its class (longest first)
-__global__ __launch_bounds__(kBlock) void pbf_runkey_kernel(const uint32_t *__restrict__ sorted_keys,
-                                                            const uint32_t *__restrict__ run_start, int64_t runs,
-                                                            uint32_t *__restrict__ rk) {
-  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (j >= runs) return;
-  const uint32_t i0 = run_start[j], len = run_start[j + 1] - i0;  // 1, 2, 4, .. 32
-  rk[j] = (sorted_keys[i0] & ~31u) | (uint32_t)(__clz(len) - 26);
-}
+struct PbSingleIn {  // 1 where run j is a single entry
+  const uint32_t *run_start;
+  __device__ __forceinline__ uint32_t operator()(int64_t j) const { return run_start[j + 1] - run_start[j] == 1u ? 1u : 0u; }
+};
 
-// cstart[e] = first sorted run of class e = piece * 6 + c (e = 0 .. 6 pieces; the last = runs)
-__global__ __launch_bounds__(kBlock) void pbf_class_start_kernel(const uint32_t *__restrict__ rks, int64_t runs,
-                                                                 int64_t classes, uint32_t *__restrict__ cstart) {
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e > classes) return;
-  const int64_t key = ((e / kPbClasses) << 5) | (e % kPbClasses);
-  int64_t lo = 0, hi = runs;
-  while (lo < hi) {
-    const int64_t mid = lo + (hi - lo) / 2;
-    if ((int64_t)rks[mid] < key) lo = mid + 1; else hi = mid;
-  }
-  cstart[e] = (uint32_t)lo;
-}
-
-// per class: its runs rounded up so that every lane's four entries are whole runs (phantom runs: value 0, trash
-// row), its entries, its steps; element `classes` of each = 0 for the exclusive scans
-__global__ __launch_bounds__(kBlock) void pbf_class_kernel(const uint32_t *__restrict__ cstart, int64_t classes,
-                                                           uint32_t *__restrict__ cls_runs, uint32_t *__restrict__ cls_ent,
-                                                           uint32_t *__restrict__ cls_steps) {
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e > classes) return;
-  uint32_t padded = 0, ent = 0;
-  if (e < classes) {
-    const uint32_t L = (uint32_t)kPbRunCap >> (e % kPbClasses), per = L >= 4 ? 1u : 4u / L;
-    padded = (cstart[e + 1] - cstart[e] + per - 1) / per * per;
-    ent = padded * L;
-  }
-  cls_runs[e] = padded;
-  cls_ent[e] = ent;
-  cls_steps[e] = (ent + kPbStepEntries - 1) / kPbStepEntries;
-}
-
-// per piece: where each of its classes' outputs begin inside it; poff[panel-major k] = its outputs, rounded up to
-// whole groups of 32
-__global__ __launch_bounds__(kBlock) void pbf_piece_kernel(const uint32_t *__restrict__ cls_runs, int64_t pieces, int64_t np,
-                                                           int64_t nb, uint32_t *__restrict__ cls_out,
-                                                           int64_t *__restrict__ poff) {
+// Order of a piece's runs: the runs of two entries and more first, the single entries behind them, each of the two
+// classes dealt by itself (the deal of pb_build_kernel, applied to runs).  On C3 two runs in three are single entries
+// (a fifth of the entries): side by side they fill whole instructions of pass 1, which then skips its segmented sums
+// (every lane a run of its own) and stores 64 neighbouring sums at once.
+// piece_run[k] = runs in front of piece k (k = 0 .. pieces); piece_long[k] = how many of piece k's runs are longer than
+// one entry; slots[k] = places of the piece: both classes rounded up to whole groups of 32, plus one place that
+// carries the piece's padding
+__global__ __launch_bounds__(kBlock) void pbf_piece_runs_kernel(const int64_t *__restrict__ piece_ptr,
+                                                                const uint32_t *__restrict__ hscan,
+                                                                const uint32_t *__restrict__ sscan, int64_t pieces,
+                                                                uint32_t *__restrict__ piece_run,
+                                                                uint32_t *__restrict__ piece_long,
+                                                                int64_t *__restrict__ slots) {
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k > pieces) return;
-  if (k == pieces) { poff[k] = 0; return; }
-  uint32_t o = 0;
-#pragma unroll
-  for (int c = 0; c < kPbClasses; c++) {
-    cls_out[k * kPbClasses + c] = o;
-    o += cls_runs[k * kPbClasses + c];
-  }
-  const int64_t b = k / np, p = k - b * np;
-  poff[p * nb + b] = ((int64_t)o + 31) & ~(int64_t)31;
+  const int64_t a = piece_ptr[k];
+  const uint32_t ra = a > 0 ? hscan[a - 1] : 0u;
+  piece_run[k] = ra;
+  if (k == pieces) { slots[k] = 0; piece_long[k] = 0; return; }
+  const int64_t b = piece_ptr[k + 1];
+  const uint32_t rb = b > 0 ? hscan[b - 1] : 0u;
+  const uint32_t singles = (rb > 0 ? sscan[rb - 1] : 0u) - (ra > 0 ? sscan[ra - 1] : 0u), longs = (rb - ra) - singles;
+  piece_long[k] = longs;
+  slots[k] = (int64_t)((longs + 31u) & ~31u) + (int64_t)((singles + 31u) & ~31u) + 1;
 }
 
-// The run at sorted place q gets its place in its class: inside a class of N runs (which the stable sort left
-// ordered by row mod 32, then row) the deal of pb_build_kernel -- G = ceil(N / 32) columns, run jl to column
-// jl mod G, the columns one behind the other -- so that 32 neighbouring outputs belong to rows of distinct row mod 32.
-__global__ __launch_bounds__(kBlock) void pbf_deal_kernel(const uint32_t *__restrict__ rks, const uint32_t *__restrict__ rperm,
-                                                          const uint32_t *__restrict__ cstart, int64_t runs,
-                                                          const uint32_t *__restrict__ run_start,
-                                                          const uint16_t *__restrict__ rr, const uint32_t *__restrict__ ebase,
-                                                          const uint32_t *__restrict__ cls_out,
-                                                          const int64_t *__restrict__ poff, int64_t np, int64_t nb,
-                                                          uint32_t *__restrict__ run_ent, uint16_t *__restrict__ row16) {
-  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (q >= runs) return;
-  const int64_t k = (int64_t)(rks[q] >> 5), c = (int64_t)(rks[q] & 31), e = k * kPbClasses + c;
-  const int64_t s = cstart[e], N = (int64_t)cstart[e + 1] - s, jl = q - s;
-  const int64_t G = (N + 31) >> 5, col = jl % G, per = N / G, rem = N % G;
-  int64_t sl = jl / G;
-  if (per + (col < rem ? 1 : 0) == 32) sl = (sl & 1) * 16 + (sl >> 1);  // a full column: neighbours (possibly one bank pair twice) into different 16-lane halves
-  const int64_t place = col * per + (col < rem ? col : rem) + sl;
-  const uint32_t j = rperm[q];
-  const int64_t b = k / np, p = k - b * np;
-  run_ent[j] = ebase[e] + (uint32_t)(place * (kPbRunCap >> c));
-  row16[poff[p * nb + b] + (int64_t)cls_out[e] + place] = rr[run_start[j]];
+// run j -> its place in its piece; len[place] = entries of the run; the piece's extra place gets its padding
+__global__ __launch_bounds__(kBlock) void pbf_slot_kernel(const uint32_t *__restrict__ sorted_keys,
+                                                          const uint32_t *__restrict__ run_start, int64_t runs,
+                                                          const uint32_t *__restrict__ piece_run,
+                                                          const uint32_t *__restrict__ piece_long,
+                                                          const uint32_t *__restrict__ sscan,
+                                                          const int64_t *__restrict__ sbase,
+                                                          const int64_t *__restrict__ piece_ptr,
+                                                          uint32_t *__restrict__ len, uint32_t *__restrict__ run_slot) {
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= runs) return;
+  const uint32_t i0 = run_start[j], n = run_start[j + 1] - i0;
+  const int64_t k = (int64_t)(sorted_keys[i0] >> 5);
+  const int64_t first = (int64_t)piece_run[k], all = (int64_t)piece_run[k + 1] - first, longs = (int64_t)piece_long[k];
+  const int64_t sb = (int64_t)sscan[j] - (first > 0 ? (int64_t)sscan[first - 1] : 0);  // single entries of the piece up to and including run j
+  const int64_t lbase = (longs + 31) & ~(int64_t)31;
+  int64_t jl, N, base;
+  if (n == 1) { jl = sb - 1; N = all - longs; base = sbase[k] + lbase; }
+  else { jl = (j - first) - sb; N = longs; base = sbase[k]; }
+  const int64_t G = (N + 31) >> 5, sl = jl / G;
+  const int64_t slot = base + (jl % G) * 32 + ((sl & 1) * 16 + (sl >> 1));
+  len[slot] = n;
+  run_slot[j] = (uint32_t)slot;
+  if (j == first) len[sbase[k] + lbase + (((all - longs) + 31) & ~(int64_t)31)] = (uint32_t)((-(piece_ptr[k + 1] - piece_ptr[k])) & 31);
 }
 
 template <class T>
 __global__ __launch_bounds__(kBlock) void pbf_place_kernel(const int32_t *__restrict__ col, const T *__restrict__ val,
-                                                           int64_t nnz, const uint32_t *__restrict__ perm,
-                                                           const uint32_t *__restrict__ rank_of_line, int64_t nb,
+                                                           int64_t nnz, const uint32_t *__restrict__ rank_of_line,
+                                                           int64_t nb, const uint32_t *__restrict__ perm,
                                                            const uint32_t *__restrict__ hscan,
                                                            const uint32_t *__restrict__ run_start,
-                                                           const uint32_t *__restrict__ run_ent, uint16_t *__restrict__ colj,
-                                                           T *__restrict__ valj) {
+                                                           const uint32_t *__restrict__ run_slot,
+                                                           const int64_t *__restrict__ spos, const uint16_t *__restrict__ rr,
+                                                           uint16_t *__restrict__ col16, T *__restrict__ pval,
+                                                           uint16_t *__restrict__ rowt) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nnz) return;
   const int64_t src = perm ? (int64_t)perm[i] : i;
   const uint32_t j = hscan[i] - 1;
-  const int64_t dst = (int64_t)run_ent[j] + (i - (int64_t)run_start[j]);
+  const uint32_t i0 = run_start[j];
+  const int64_t pos = spos[run_slot[j]] + (i - (int64_t)i0);
   const int32_t c = col[src];
   const int64_t q = rank_of_line[c / kPbLine];
-  colj[dst] = (uint16_t)((q / nb) * kPbLine + (c % kPbLine));
-  valj[dst] = val[src];
+  const bool head = i == (int64_t)i0 || (pos & (kPbRunCap - 1)) == 0;
+  col16[pos] = (uint16_t)(((q / nb) * kPbLine + (c % kPbLine)) | (head ? 0x8000 : 0));
+  pval[pos] = val[src];
+  rowt[pos] = rr[i];
 }
 
-// the steps of every class
-__global__ __launch_bounds__(kBlock) void pbf_desc_kernel(const uint32_t *__restrict__ cls_ent, const uint32_t *__restrict__ ebase,
-                                                          const uint32_t *__restrict__ stbase,
-                                                          const uint32_t *__restrict__ cls_out, const int64_t *__restrict__ poff,
-                                                          int64_t classes, int64_t np, int64_t nb, uint32_t *__restrict__ desc) {
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (e >= classes) return;
-  const uint32_t ent = cls_ent[e];
-  if (ent == 0) return;
-  const int64_t k = e / kPbClasses, c = e % kPbClasses, b = k / np, p = k - b * np;
-  const uint32_t ob = (uint32_t)(poff[p * nb + b] + (int64_t)cls_out[e]), L = (uint32_t)kPbRunCap >> c;
-  uint32_t *d = desc + 4 * (int64_t)stbase[e];
-  for (uint32_t done = 0; done < ent; done += kPbStepEntries, d += 4) {
-    const uint32_t left = ent - done;
-    d[0] = ebase[e] + done;
-    d[1] = ob + done / L;
-    d[2] = (left >= (uint32_t)kPbStepEntries ? 64u : left / 4) | ((uint32_t)c << 8);
-    d[3] = 0;
+// per piece: its first pad starts the trash run; heads per group counted afterwards
+__global__ __launch_bounds__(kBlock) void pbf_padhead_kernel(const int64_t *__restrict__ piece_ptr,
+                                                             const uint32_t *__restrict__ piece_run,
+                                                             const uint32_t *__restrict__ piece_long,
+                                                             const int64_t *__restrict__ sbase,
+                                                             const int64_t *__restrict__ spos, int64_t pieces,
+                                                             uint16_t *__restrict__ col16) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= pieces) return;
+  if (((piece_ptr[k + 1] - piece_ptr[k]) & 31) == 0) return;
+  const int64_t all = (int64_t)piece_run[k + 1] - (int64_t)piece_run[k], longs = (int64_t)piece_long[k];
+  col16[spos[sbase[k] + ((longs + 31) & ~(int64_t)31) + (((all - longs) + 31) & ~(int64_t)31)]] = 0x8000;
+}
+
+__global__ __launch_bounds__(kBlock) void pbf_group_heads_kernel(const uint16_t *__restrict__ col16, int64_t groups,
+                                                                 uint32_t *__restrict__ cnt) {
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g > groups) return;
+  uint32_t n = 0;
+  if (g < groups) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(col16 + g * 32);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint4 w = p[q];
+      n += __popc(w.x & 0x80008000u) + __popc(w.y & 0x80008000u) + __popc(w.z & 0x80008000u) + __popc(w.w & 0x80008000u);
+    }
   }
+  cnt[g] = n;  // element `groups` = 0: the exclusive scan leaves the total there
 }
 
-// bounds[0 .. nb]: block b's first step; then [0 .. np]: panel p's first output
-__global__ __launch_bounds__(kBlock) void pbf_bounds_kernel(const uint32_t *__restrict__ stbase, const int64_t *__restrict__ poff,
-                                                            int64_t np, int64_t nb, int64_t *__restrict__ bounds) {
+// outputs of every piece, rounded up (pass 1's stores like a piece to start on a line; the pads cost pass 2 nothing
+// but their bytes since each of an instruction's pads has a trash slot of its own: with one shared slot they took
+// 16 turns on it and pass 2 ran 0.325 ms instead of 0.260), written where the panel-major scan wants them
+__global__ __launch_bounds__(kBlock) void pbf_osz_kernel(const int64_t *__restrict__ sbase, const int64_t *__restrict__ spos,
+                                                         const uint32_t *__restrict__ hx, int64_t pieces, int64_t np,
+                                                         int64_t nb, uint32_t round, int64_t *__restrict__ poff) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k > pieces) return;
+  if (k == pieces) { poff[k] = 0; return; }
+  const int64_t g0 = spos[sbase[k]] >> 5, g1 = spos[sbase[k + 1]] >> 5;
+  const int64_t b = k / np, p = k - b * np;
+  poff[p * nb + b] = (int64_t)((hx[g1] - hx[g0] + round - 1u) / round * round);
+}
+
+// A panel's products start on a multiple of 64: pass 2 reads them 64 at a time (128 bytes of rows, 256 of sums per
+// instruction), and instructions that share a line make the second wait in the L1 for the line the first asked for.
+__global__ __launch_bounds__(kBlock) void pbf_panel_align_kernel(int64_t np, int64_t nb, int64_t *__restrict__ poff) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= np) return;
+  int64_t sum = 0;
+  for (int64_t b = 0; b < nb; b++) sum += poff[p * nb + b];
+  poff[p * nb + nb - 1] += (-sum) & 63;
+}
+
+__global__ __launch_bounds__(kBlock) void pbf_uout_kernel(const int64_t *__restrict__ sbase, const int64_t *__restrict__ spos,
+                                                          const uint32_t *__restrict__ hx, const int64_t *__restrict__ poff,
+                                                          int64_t pieces, int64_t np, int64_t nb,
+                                                          uint32_t *__restrict__ uout) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= pieces) return;
+  const int64_t g0 = spos[sbase[k]] >> 5, g1 = spos[sbase[k + 1]] >> 5;
+  const int64_t b = k / np, p = k - b * np;
+  const int64_t base = poff[p * nb + b];
+  const uint32_t h0 = hx[g0];
+  for (int64_t g = g0; g < g1; g++) uout[g] = (uint32_t)(base + (int64_t)(hx[g] - h0));
+}
+
+// the row of every output, where pass 2 streams it
+__global__ __launch_bounds__(kBlock) void pbf_rows_out_kernel(const uint16_t *__restrict__ col16,
+                                                              const uint16_t *__restrict__ rowt, int64_t ptotal,
+                                                              const uint32_t *__restrict__ uout,
+                                                              uint16_t *__restrict__ row16) {
+  const int64_t pos = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // ptotal is a multiple of 32, blocks of 256
+  const bool ok = pos < ptotal;
+  const bool head = ok && (col16[pos] & 0x8000) != 0;
+  const unsigned long long heads = __ballot(head);
+  if (head) row16[(int64_t)uout[pos >> 5] + pb_rank_in_half(heads, (int)(threadIdx.x & 63))] = rowt[pos];
+}
+
+__global__ __launch_bounds__(kBlock) void pbf_bounds_kernel(const int64_t *__restrict__ sbase, const int64_t *__restrict__ spos,
+                                                            const int64_t *__restrict__ poff, int64_t np, int64_t nb,
+                                                            int64_t *__restrict__ bounds) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i <= nb) bounds[i] = (int64_t)stbase[i * np * kPbClasses];
+  if (i <= nb) bounds[i] = spos[sbase[i * np]];
   else if (i <= nb + 1 + np) bounds[i] = poff[(i - nb - 1) * nb];
 }
 
-// ---- pass 1 of the folded layout: workgroup = kPbWaves consecutive wavefront ranges of one column block (its slice
-// of x in LDS), wavefront = a range of steps, walked a batch at a time; the descriptors of batch g + 2 and the
-// entries of batch g + 1 are requested before batch g is summed.  Every step loads 256 entries whatever its count
-// (behind the array: slack), so no load is predicated; the stores go through a buffer whose range is the step's
-// outputs, so the lanes behind them are dropped by the address check, not by a branch.
-typedef unsigned int pb_u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int pb_u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kPbRsrcFlags = 0x00020000;  // gfx9 raw buffer, 32-bit data format
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pb_rsrc(const void *base, int bytes = 0x7ffffffe) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, kPbRsrcFlags);
-}
-
-template <int CTRL, class T>
-__device__ __forceinline__ T pb_dpp0(T v) {  // lanes without a source read 0
-  if constexpr (sizeof(T) == 4) {
-    return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-  } else {
-    const uint64_t u = __builtin_bit_cast(uint64_t, v);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
-    return __builtin_bit_cast(T, ((uint64_t)hi << 32) | lo);
-  }
-}
-
-template <class T>
-struct PbStepRegs {  // a lane's four entries of one step
-  pb_u32x2 c;                       // four 16-bit columns
-  pb_u32x4 v[sizeof(T) / 4];        // four values
-  __device__ __forceinline__ uint32_t col(int k) const { return (k & 1) ? c[k >> 1] >> 16 : c[k >> 1] & 0xffffu; }
-  __device__ __forceinline__ T val(int k) const {
-    if constexpr (sizeof(T) == 4) {
-      const uint32_t w = v[0][k];  // (a bit cast of the element expression itself reads element 0: clang 20)
-      return __builtin_bit_cast(T, w);
-    } else {
-      const uint64_t w = ((uint64_t)v[k >> 1][(k & 1) * 2 + 1] << 32) | v[k >> 1][(k & 1) * 2];
-      return __builtin_bit_cast(T, w);
-    }
-  }
-};
-
-template <int AUX, int N, class T>
-__device__ __forceinline__ void pb_bstore_n(const T (&x)[N], __amdgpu_buffer_rsrc_t r, int off) {  // N consecutive elements
-  constexpr int W = N * (int)sizeof(T) / 4;  // dwords: 1, 2, 4 or 8
-  uint32_t w[W];
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    if constexpr (sizeof(T) == 4) {
-      w[k] = __builtin_bit_cast(uint32_t, x[k]);
-    } else {
-      const uint64_t u = __builtin_bit_cast(uint64_t, x[k]);
-      w[2 * k] = (uint32_t)u;
-      w[2 * k + 1] = (uint32_t)(u >> 32);
-    }
-  }
-  if constexpr (W == 1) {
-    __builtin_amdgcn_raw_buffer_store_b32(w[0], r, off, 0, AUX);
-  } else if constexpr (W == 2) {
-    const pb_u32x2 t = {w[0], w[1]};
-    __builtin_amdgcn_raw_buffer_store_b64(t, r, off, 0, AUX);
-  } else {
-#pragma unroll
-    for (int h = 0; h < W / 4; h++) {
-      const pb_u32x4 t = {w[4 * h], w[4 * h + 1], w[4 * h + 2], w[4 * h + 3]};
-      __builtin_amdgcn_raw_buffer_store_b128(t, r, off + 16 * h, 0, AUX);
-    }
-  }
-}
-
-// LAB (kernel lab; results wrong for 1 and 2): 1 no store, 2 no LDS gather, 3 non-temporal stores
-template <class T, int LAB>
-__global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__restrict__ wtab,
-                                                               const uint32_t *__restrict__ desc,
-                                                               const uint16_t *__restrict__ colj,
-                                                               const T *__restrict__ valj, const T *__restrict__ xperm,
-                                                               T *__restrict__ prod, int w) {
-  __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
-  constexpr int B = sizeof(T) == 4 ? 4 : 2;  // steps per batch
-  constexpr int AUXS = LAB == 3 ? 2 : 0;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t r = (int64_t)blockIdx.x * kPbWaves + wave;
-  const int64_t b = wtab[2 * (int64_t)blockIdx.x * kPbWaves + 1];
-  const int64_t step0 = wtab[2 * r], step1 = wtab[2 * r + 2];
-  const int nsteps = (int)(step1 - step0), nbat = (nsteps + B - 1) / B;
-  // descriptors through a range-checked buffer: the steps behind the range read as zeros, i.e. no lanes
-  const __amdgpu_buffer_rsrc_t rd = pb_rsrc(desc + 4 * step0, nsteps > 0 ? nsteps * 16 : 0);
-  // batch g = step g of each of the range's B quarters: steps that are neighbours in memory share a line of each
-  // array, and a load that meets a line still on its way stalls the L1 (TCP_PENDING_STALL_CYCLES); this way they are
-  // a whole batch apart
-  auto dload = [&](int g) -> pb_u32x4 {  // lane u (mod B) gets step u nbat + g
-    const int idx = g < nbat ? (lane & (B - 1)) * nbat + g : nsteps;  // behind the range: zeros
-    return __builtin_amdgcn_raw_buffer_load_b128(rd, idx * 16, 0, 0);
-  };
-  auto issue = [&](const pb_u32x4 d, PbStepRegs<T> (&e)[B]) {
-#pragma unroll
-    for (int u = 0; u < B; u++) {
-      // a buffer per step whose range ends with the step's last lane: the lanes behind it read zeros and ask for
-      // nothing (asking anyway -- the next step's lines -- made that step's own loads wait on lines already
-      // pending: TCP_PENDING_STALL_CYCLES as large as the kernel itself)
-      const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)d.x, u);
-      const int lanes = __builtin_amdgcn_readlane((int)d.z, u) & 0xff;
-      const __amdgpu_buffer_rsrc_t rc = pb_rsrc(colj + off, lanes * 8), rv = pb_rsrc(valj + off, lanes * 4 * (int)sizeof(T));
-      e[u].c = __builtin_amdgcn_raw_buffer_load_b64(rc, lane * 8, 0, 2);  // aux 2: non-temporal
-#pragma unroll
-      for (int h = 0; h < (int)sizeof(T) / 4; h++)
-        e[u].v[h] = __builtin_amdgcn_raw_buffer_load_b128(rv, lane * 4 * (int)sizeof(T) + 16 * h, 0, 2);
-    }
-  };
-  auto consume = [&](const pb_u32x4 d, const PbStepRegs<T> (&e)[B]) {
-    T p[B][4];
-#pragma unroll
-    for (int u = 0; u < B; u++)
-#pragma unroll
-      for (int k = 0; k < 4; k++) p[u][k] = LAB == 2 ? e[u].val(k) : (T)(e[u].val(k) * xs[e[u].col(k)]);
-#pragma unroll
-    for (int u = 0; u < B; u++) {
-      const uint32_t ob = (uint32_t)__builtin_amdgcn_readlane((int)d.y, u);
-      const int meta = __builtin_amdgcn_readlane((int)d.z, u);
-      const int lanes = meta & 0xff, c = meta >> 8;  // class c: runs of 32 >> c entries
-      if (LAB == 1 && p[u][0] != (T)12345) continue;
-      // the step's outputs: 4 lanes / L of them; the lanes behind them are out of the buffer's range and dropped
-      const __amdgpu_buffer_rsrc_t rp = pb_rsrc(prod + ob, ((lanes * 4) >> (5 - c)) * (int)sizeof(T));
-      if (c == 5) {
-        pb_bstore_n<AUXS, 4>(p[u], rp, lane * 4 * (int)sizeof(T));
-      } else if (c == 4) {
-        const T s2[2] = {(T)(p[u][0] + p[u][1]), (T)(p[u][2] + p[u][3])};
-        pb_bstore_n<AUXS, 2>(s2, rp, lane * 2 * (int)sizeof(T));
-      } else {
-        T s1[1] = {(T)((T)(p[u][0] + p[u][1]) + (T)(p[u][2] + p[u][3]))};
-        if (c == 3) {
-          pb_bstore_n<AUXS, 1>(s1, rp, lane * (int)sizeof(T));
-        } else {  // a run is 2, 4 or 8 neighbouring lanes: its last lane collects
-          s1[0] = (T)(s1[0] + pb_dpp0<0x111>(s1[0]));                // row_shr:1
-          if (c <= 1) s1[0] = (T)(s1[0] + pb_dpp0<0x112>(s1[0]));    // row_shr:2
-          if (c == 0) s1[0] = (T)(s1[0] + pb_dpp0<0x114>(s1[0]));    // row_shr:4
-          const int per = 8 >> c;  // lanes per run
-          if ((lane & (per - 1)) == per - 1) pb_bstore_n<AUXS, 1>(s1, rp, (lane >> (3 - c)) * (int)sizeof(T));
-        }
-      }
-    }
-  };
-  pb_u32x4 d0 = dload(0), d1 = dload(1), d2 = dload(2);
-  {
-    constexpr int PER = 16 / (int)sizeof(T);
-    const raw16 *src = reinterpret_cast<const raw16 *>(xperm + b * (int64_t)w);
-    for (int j = threadIdx.x; j < w / PER; j += kPbThreads) reinterpret_cast<raw16 *>(xs)[j] = src[j];
-  }
-  PbStepRegs<T> ea[B], eb[B];
-  issue(d0, ea);
-  __syncthreads();
-  for (int g = 0; g < nbat; g += 2) {
-    const pb_u32x4 d3 = dload(g + 3);
-    issue(d1, eb);
-    consume(d0, ea);
-    const pb_u32x4 d4 = dload(g + 4);
-    issue(d2, ea);
-    consume(d1, eb);
-    d0 = d2;
-    d1 = d3;
-    d2 = d4;
-  }
-}
-
-// Builds the folded layout from the entries sorted by (piece, row mod 32, row, column).  *done = false (and nothing
-// kept) when folding would not shorten the product stream enough, or the sizes leave the 32-bit indices.
+// Builds the folded layout from the sorted entries.  *done = false (and nothing kept) when folding would not shorten
+// the product stream enough, or the sizes leave the 32-bit indices.
 template <class T>
 int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, const uint32_t *eperm,
               const int64_t *piece_ptr, const int64_t *panel_row, const uint32_t *rank_of_line, int64_t nb, int64_t np,
               int64_t pieces, bool sorted, bool *done) {
   *done = false;
   const int64_t nnz = a->nnz;
-  const unsigned egrid = (unsigned)cdiv(nnz, kBlock);
-  int *sort_err = reinterpret_cast<int *>(ctx->d_small + 2);
+  const unsigned egrid = (unsigned)cdiv(nnz, kBlock), pgrid = (unsigned)cdiv(pieces + 1, kBlock);
   Tmp<uint16_t> rr(ctx);
-  Tmp<uint32_t> hscan(ctx), run_start(ctx);
+  Tmp<uint32_t> hscan(ctx);
   SAMD_TRY(rr.get(nnz));
   SAMD_TRY(hscan.get(nnz));
   hipLaunchKernelGGL(pbf_rows_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, (const int64_t *)a->row_ptr, nnz,
                      (const int64_t *)a->tile_lb, a->tile, panel_row, np, eks, eperm, rr.p);
   SAMD_LAUNCH_CHECK(ctx);
+  const PbRunHeadIn head{eks, rr.p};
   uint32_t *d_runs = reinterpret_cast<uint32_t *>(ctx->d_small + 4);
+  SAMD_TRY((device_scan<uint32_t, OpAdd, PbRunHeadIn, false>(ctx, head, nnz, 0u, OpAdd(), hscan.p, d_runs)));
   int64_t small[8];
-  int64_t runs = 0;
-  {
-    // ---- a row's entries inside a piece, then the runs they are cut into
-    Tmp<uint32_t> id0(ctx), row_start(ctx);
-    SAMD_TRY(id0.get(nnz));
-    const PbRunHeadIn head0{eks, rr.p};
-    SAMD_TRY((device_scan<uint32_t, OpAdd, PbRunHeadIn, false>(ctx, head0, nnz, 0u, OpAdd(), id0.p, d_runs)));
-    SAMD_TRY(read_small(ctx, ctx->d_small, 5, small));
-    const int64_t rows0 = (int64_t)(uint32_t)(small[4] & 0xffffffff);
-    if (ctx->logging) fprintf(stderr, "[sparse_amd] two-pass SpMV: %lld rows-in-pieces for %lld entries\n", (long long)rows0, (long long)nnz);
-    // not worth the fold?  (With sorted blocks there is no other layout: the plain pass 1 splits every block into the
-    // same number of shares.)
-    if (!sorted && ctx->opt_spmv_pb_fold <= 0 && (double)rows0 > 0.85 * (double)nnz) return 0;
-    SAMD_TRY(row_start.get(rows0 + 1));
-    hipLaunchKernelGGL((pbf_starts_kernel<PbRunHeadIn>), dim3(egrid), dim3(kBlock), 0, ctx->stream, head0, (const uint32_t *)id0.p,
-                       nnz, row_start.p);
-    SAMD_LAUNCH_CHECK(ctx);
-    const PbSubHeadIn head{id0.p, row_start.p};
-    SAMD_TRY((device_scan<uint32_t, OpAdd, PbSubHeadIn, false>(ctx, head, nnz, 0u, OpAdd(), hscan.p, d_runs)));
-    SAMD_TRY(read_small(ctx, ctx->d_small, 5, small));
-    runs = (int64_t)(uint32_t)(small[4] & 0xffffffff);
-    if (runs + 64 * pieces >= (int64_t)0xffffff00LL) return 0;  // 32-bit places and outputs
-    SAMD_TRY(run_start.get(runs + 1));
-    hipLaunchKernelGGL((pbf_starts_kernel<PbSubHeadIn>), dim3(egrid), dim3(kBlock), 0, ctx->stream, head,
-                       (const uint32_t *)hscan.p, nnz, run_start.p);
-    SAMD_LAUNCH_CHECK(ctx);
-    SAMD_TRY(read_small(ctx, ctx->d_small, 1, small));  // id0 and row_start are released after their use
-  }
-  // ---- the runs sorted by (piece, class); classes, their entries, steps and outputs
-  const int64_t classes = pieces * kPbClasses;
-  const unsigned cgrid = (unsigned)cdiv(classes + 1, kBlock), rgrid = (unsigned)cdiv(runs, kBlock);
-  Tmp<uint32_t> rk_a(ctx), rk_b(ctx), rp_a(ctx), rp_b(ctx), cstart(ctx), cls_runs(ctx), cls_ent(ctx), ebase(ctx), stbase(ctx),
-      cls_out(ctx), run_ent(ctx);
+  SAMD_TRY(read_small(ctx, ctx->d_small, 5, small));
+  const int64_t runs = (int64_t)(uint32_t)(small[4] & 0xffffffff);
+  if (ctx->logging) fprintf(stderr, "[sparse_amd] two-pass SpMV: %lld runs for %lld entries\n", (long long)runs, (long long)nnz);
+  // not worth the fold arithmetic?  (With sorted blocks there is no other layout: the plain pass 1 splits every block
+  // into the same number of shares.)
+  if (!sorted && ctx->opt_spmv_pb_fold <= 0 && (double)runs > 0.85 * (double)nnz) return 0;
+  if (runs + 65 * pieces >= (int64_t)0xffffff00LL) return 0;                      // 32-bit places and outputs
+  Tmp<uint32_t> run_start(ctx), piece_run(ctx), run_slot(ctx), len(ctx);
+  Tmp<int64_t> sbase(ctx), spos(ctx);
+  SAMD_TRY(run_start.get(runs + 1));
+  SAMD_TRY(piece_run.get(pieces + 1));
+  SAMD_TRY(run_slot.get(runs));
+  SAMD_TRY(sbase.get(pieces + 1));
+  hipLaunchKernelGGL(pbf_runstart_kernel, dim3(egrid), dim3(kBlock), 0, ctx->stream, head, (const uint32_t *)hscan.p, nnz,
+                     run_start.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  Tmp<uint32_t> sscan(ctx), piece_long(ctx);
+  SAMD_TRY(sscan.get(runs));
+  SAMD_TRY(piece_long.get(pieces + 1));
+  SAMD_TRY((device_scan<uint32_t, OpAdd, PbSingleIn, false>(ctx, PbSingleIn{run_start.p}, runs, 0u, OpAdd(), sscan.p,
+                                                             (uint32_t *)nullptr)));
+  hipLaunchKernelGGL(pbf_piece_runs_kernel, dim3(pgrid), dim3(kBlock), 0, ctx->stream, piece_ptr, (const uint32_t *)hscan.p,
+                     (const uint32_t *)sscan.p, pieces, piece_run.p, piece_long.p, sbase.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  SAMD_TRY((device_scan<int64_t, OpAdd, PtrIn<int64_t>, true>(ctx, PtrIn<int64_t>{sbase.p}, pieces + 1, (int64_t)0, OpAdd(),
+                                                               sbase.p, (int64_t *)nullptr)));
+  SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small, sbase.p + pieces, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, small));
+  const int64_t places = small[0];  // all pieces' places in the dealt order
+  SAMD_TRY(len.get(places + 1));
+  SAMD_TRY(spos.get(places + 1));
+  SAMD_HIP(ctx, hipMemsetAsync(len.p, 0, sizeof(uint32_t) * (size_t)(places + 1), ctx->stream));
+  hipLaunchKernelGGL(pbf_slot_kernel, dim3((unsigned)cdiv(runs, kBlock)), dim3(kBlock), 0, ctx->stream, eks,
+                     (const uint32_t *)run_start.p, runs, (const uint32_t *)piece_run.p, (const uint32_t *)piece_long.p,
+                     (const uint32_t *)sscan.p, (const int64_t *)sbase.p, piece_ptr, len.p, run_slot.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  SAMD_TRY((device_scan<int64_t, OpAdd, PbU32AsI64In, true>(ctx, PbU32AsI64In{len.p}, places + 1, (int64_t)0, OpAdd(), spos.p,
+                                                             (int64_t *)nullptr)));
+  SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small, spos.p + places, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, small));
+  const int64_t ptotal = small[0];  // entries of the block-major layout, pads included: a multiple of 32
+  const int64_t groups = ptotal >> 5;
+  if ((ptotal & 31) != 0) return set_error(ctx, "internal: folded two-pass layout is not made of whole groups");
+  Tmp<uint16_t> col16(ctx), rowt(ctx), row16(ctx);
+  Tmp<T> pval(ctx), prod(ctx), xperm(ctx);
+  Tmp<uint32_t> hx(ctx), uout(ctx);
   Tmp<int64_t> poff(ctx), bounds(ctx);
-  SAMD_TRY(rk_a.get(runs));
-  SAMD_TRY(rk_b.get(runs));
-  SAMD_TRY(rp_a.get(runs));
-  SAMD_TRY(rp_b.get(runs));
-  SAMD_TRY(cstart.get(classes + 1));
-  SAMD_TRY(cls_runs.get(classes + 1));
-  SAMD_TRY(cls_ent.get(classes + 1));
-  SAMD_TRY(ebase.get(classes + 1));
-  SAMD_TRY(stbase.get(classes + 1));
-  SAMD_TRY(cls_out.get(classes + 1));
-  SAMD_TRY(run_ent.get(runs));
+  SAMD_TRY(col16.get(ptotal));
+  SAMD_TRY(rowt.get(ptotal));
+  SAMD_TRY(pval.get(ptotal));
+  SAMD_TRY(hx.get(groups + 1));
+  SAMD_TRY(uout.get(groups));
   SAMD_TRY(poff.get(pieces + 1));
   SAMD_TRY(bounds.get(nb + 1 + np + 1));
-  hipLaunchKernelGGL(pbf_runkey_kernel, dim3(rgrid), dim3(kBlock), 0, ctx->stream, eks, (const uint32_t *)run_start.p, runs, rk_a.p);
+  SAMD_HIP(ctx, hipMemsetAsync(col16.p, 0, sizeof(uint16_t) * (size_t)ptotal, ctx->stream));
+  SAMD_HIP(ctx, hipMemsetAsync(pval.p, 0, sizeof(T) * (size_t)ptotal, ctx->stream));
+  SAMD_HIP(ctx, hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(rowt.p), (unsigned short)PbSlice<T>::kRows, (size_t)ptotal,
+                                  ctx->stream));
+  hipLaunchKernelGGL((pbf_place_kernel<T>), dim3(egrid), dim3(kBlock), 0, ctx->stream, (const int32_t *)a->col32,
+                     (const T *)a->vals, nnz, rank_of_line, nb, eperm, (const uint32_t *)hscan.p, (const uint32_t *)run_start.p,
+                     (const uint32_t *)run_slot.p, (const int64_t *)spos.p, (const uint16_t *)rr.p, col16.p, pval.p, rowt.p);
   SAMD_LAUNCH_CHECK(ctx);
-  uint32_t *rks = nullptr;
-  const uint32_t *rperm = nullptr;
-  SAMD_TRY((radix_sort_pairs<uint32_t, uint32_t>(ctx, rk_a.p, rk_b.p, (const uint32_t *)nullptr, rp_a.p, rp_b.p, runs, 0,
-                                                  bits_for(pieces) + 5, &rks, &rperm, sort_err)));
-  hipLaunchKernelGGL(pbf_class_start_kernel, dim3(cgrid), dim3(kBlock), 0, ctx->stream, (const uint32_t *)rks, runs, classes,
-                     cstart.p);
+  hipLaunchKernelGGL(pbf_padhead_kernel, dim3(pgrid), dim3(kBlock), 0, ctx->stream, piece_ptr, (const uint32_t *)piece_run.p,
+                     (const uint32_t *)piece_long.p,
+                     (const int64_t *)sbase.p, (const int64_t *)spos.p, pieces, col16.p);
   SAMD_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(pbf_class_kernel, dim3(cgrid), dim3(kBlock), 0, ctx->stream, (const uint32_t *)cstart.p, classes, cls_runs.p,
-                     cls_ent.p, stbase.p);
+  hipLaunchKernelGGL(pbf_group_heads_kernel, dim3((unsigned)cdiv(groups + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     (const uint16_t *)col16.p, groups, hx.p);
   SAMD_LAUNCH_CHECK(ctx);
-  uint32_t *d_tot = reinterpret_cast<uint32_t *>(ctx->d_small);  // [0]: entries (64-bit slot 0), [2]: steps (64-bit slot 1)
-  SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, 2 * sizeof(int64_t), ctx->stream));
-  SAMD_TRY((device_scan<uint32_t, OpAdd, PtrIn<uint32_t>, true>(ctx, PtrIn<uint32_t>{cls_ent.p}, classes + 1, 0u, OpAdd(), ebase.p,
-                                                                 d_tot)));
-  SAMD_TRY((device_scan<uint32_t, OpAdd, PtrIn<uint32_t>, true>(ctx, PtrIn<uint32_t>{stbase.p}, classes + 1, 0u, OpAdd(),
-                                                                 stbase.p, d_tot + 2)));
-  hipLaunchKernelGGL(pbf_piece_kernel, dim3((unsigned)cdiv(pieces + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
-                     (const uint32_t *)cls_runs.p, pieces, np, nb, cls_out.p, poff.p);
+  SAMD_TRY((device_scan<uint32_t, OpAdd, PtrIn<uint32_t>, true>(ctx, PtrIn<uint32_t>{hx.p}, groups + 1, 0u, OpAdd(), hx.p,
+                                                                 (uint32_t *)nullptr)));
+  hipLaunchKernelGGL(pbf_osz_kernel, dim3(pgrid), dim3(kBlock), 0, ctx->stream, (const int64_t *)sbase.p, (const int64_t *)spos.p,
+                     (const uint32_t *)hx.p, pieces, np, nb,
+                     (uint32_t)(ctx->opt_spmv_pb_oround > 0 ? ctx->opt_spmv_pb_oround : kPbOutRound), poff.p);
+  SAMD_LAUNCH_CHECK(ctx);
+  hipLaunchKernelGGL(pbf_panel_align_kernel, dim3((unsigned)cdiv(np, kBlock)), dim3(kBlock), 0, ctx->stream, np, nb, poff.p);
   SAMD_LAUNCH_CHECK(ctx);
   SAMD_TRY((device_scan<int64_t, OpAdd, PtrIn<int64_t>, true>(ctx, PtrIn<int64_t>{poff.p}, pieces + 1, (int64_t)0, OpAdd(),
                                                                poff.p, (int64_t *)nullptr)));
-  SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small + 3, poff.p + pieces, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
-  SAMD_TRY(read_small(ctx, ctx->d_small, 4, small));
-  if ((int)(small[2] & 0xffffffff) != 0) return set_error(ctx, "internal: radix sort look-back timed out");
-  const int64_t etotal = (int64_t)(uint32_t)(small[0] & 0xffffffff), nsteps = (int64_t)(uint32_t)(small[1] & 0xffffffff);
-  const int64_t ototal = small[3];  // entries (phantom runs included), steps, outputs (pads included)
-  if (ctx->logging)
-    fprintf(stderr, "[sparse_amd] two-pass SpMV, folded: %lld runs, %lld entries laid out, %lld steps (%.0f entries per step), %lld products\n",
-            (long long)runs, (long long)etotal, (long long)nsteps, (double)etotal / (double)(nsteps > 0 ? nsteps : 1), (long long)ototal);
-  // 32-bit byte offsets in pass 1 (a wrapped 32-bit entry total shows as fewer entries than the record has)
-  if (ototal >= (int64_t)0x7fffff00LL || etotal < nnz || (etotal + 1024) * (int64_t)sizeof(T) >= (int64_t)0xffffff00LL) return 0;
-  // ---- the layout itself
-  constexpr int64_t kSlack = 512;  // a step loads 256 entries whatever its count
-  Tmp<uint32_t> desc(ctx);
-  Tmp<uint16_t> colj(ctx), row16(ctx);
-  Tmp<T> valj(ctx), prod(ctx);
-  SAMD_TRY(desc.get(4 * nsteps));
-  SAMD_TRY(colj.get(etotal + kSlack));
-  SAMD_TRY(valj.get(etotal + kSlack));
+  SAMD_HIP(ctx, hipMemcpyAsync(ctx->d_small, poff.p + pieces, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  SAMD_TRY(read_small(ctx, ctx->d_small, 1, small));
+  const int64_t ototal = small[0];  // outputs
+  if (ototal >= (int64_t)0xffffff00LL) return 0;
   SAMD_TRY(row16.get(ototal));
-  SAMD_TRY(prod.get(ototal));
-  SAMD_HIP(ctx, hipMemsetAsync(colj.p, 0, sizeof(uint16_t) * (size_t)(etotal + kSlack), ctx->stream));  // phantom runs: column 0, value 0
-  SAMD_HIP(ctx, hipMemsetAsync(valj.p, 0, sizeof(T) * (size_t)(etotal + kSlack), ctx->stream));
-  SAMD_HIP(ctx, hipMemsetAsync(prod.p, 0, sizeof(T) * (size_t)ototal, ctx->stream));  // a piece's pads (up to the next group of 32) are read by pass 2, into the trash slots
-  if (ototal > 0) {
-    hipLaunchKernelGGL(pb_fill_trash_kernel, dim3((unsigned)cdiv(ototal, kBlock)), dim3(kBlock), 0, ctx->stream, row16.p, ototal,
-                       (int)PbSlice<T>::kRows);  // pads and phantom runs: the trash slots behind the slice
-    SAMD_LAUNCH_CHECK(ctx);
-  }
-  hipLaunchKernelGGL(pbf_deal_kernel, dim3(rgrid), dim3(kBlock), 0, ctx->stream, (const uint32_t *)rks, rperm,
-                     (const uint32_t *)cstart.p, runs, (const uint32_t *)run_start.p, (const uint16_t *)rr.p,
-                     (const uint32_t *)ebase.p, (const uint32_t *)cls_out.p, (const int64_t *)poff.p, np, nb, run_ent.p, row16.p);
+  hipLaunchKernelGGL(pb_fill_trash_kernel, dim3((unsigned)cdiv(ototal, kBlock)), dim3(kBlock), 0, ctx->stream, row16.p, ototal,
+                     (int)PbSlice<T>::kRows);
   SAMD_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL((pbf_place_kernel<T>), dim3(egrid), dim3(kBlock), 0, ctx->stream, (const int32_t *)a->col32,
-                     (const T *)a->vals, nnz, eperm, rank_of_line, nb, (const uint32_t *)hscan.p, (const uint32_t *)run_start.p,
-                     (const uint32_t *)run_ent.p, colj.p, valj.p);
+  hipLaunchKernelGGL(pbf_uout_kernel, dim3((unsigned)cdiv(pieces, kBlock)), dim3(kBlock), 0, ctx->stream, (const int64_t *)sbase.p,
+                     (const int64_t *)spos.p, (const uint32_t *)hx.p, (const int64_t *)poff.p, pieces, np, nb, uout.p);
   SAMD_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL(pbf_desc_kernel, dim3((unsigned)cdiv(classes, kBlock)), dim3(kBlock), 0, ctx->stream,
-                     (const uint32_t *)cls_ent.p, (const uint32_t *)ebase.p, (const uint32_t *)stbase.p,
-                     (const uint32_t *)cls_out.p, (const int64_t *)poff.p, classes, np, nb, desc.p);
+  hipLaunchKernelGGL(pbf_rows_out_kernel, dim3((unsigned)cdiv(ptotal, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     (const uint16_t *)col16.p, (const uint16_t *)rowt.p, ptotal, (const uint32_t *)uout.p, row16.p);
   SAMD_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(pbf_bounds_kernel, dim3((unsigned)cdiv(nb + 1 + np + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
-                     (const uint32_t *)stbase.p, (const int64_t *)poff.p, np, nb, bounds.p);
+                     (const int64_t *)sbase.p, (const int64_t *)spos.p, (const int64_t *)poff.p, np, nb, bounds.p);
   SAMD_LAUNCH_CHECK(ctx);
+  SAMD_TRY(prod.get(ototal + 64));  // behind the outputs: the trash the pads of the chunked layout write to
+  SAMD_HIP(ctx, hipMemsetAsync(prod.p, 0, sizeof(T) * (size_t)(ototal + 64), ctx->stream));  // output pads are read by pass 2 (into the trash slots)
+  // ---- the chunked layout pass 1 reads, and pass 1's shares: about four workgroups per CU, every block cut into
+  // shares of whole chunks in proportion to its entries (at least one)
   std::vector<int64_t> hb((size_t)nb + 1);
   SAMD_HIP(ctx, hipMemcpyAsync(hb.data(), bounds.p, sizeof(int64_t) * (size_t)(nb + 1), hipMemcpyDeviceToHost, ctx->stream));
   SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  // ---- pass 1's wavefront ranges: about four workgroups per CU, every block cut into workgroups in proportion to
-  // its steps (at least one), every workgroup's steps into kPbWaves ranges.  wtab[r] = {first step, block}
-  std::vector<int64_t> wt;
+  std::vector<int64_t> wt, cb((size_t)nb + 1);
+  cb[0] = 0;
+  for (int64_t b = 0; b < nb; b++) cb[(size_t)b + 1] = cb[(size_t)b] + cdiv(hb[(size_t)b + 1] - hb[(size_t)b], kPbChunk);
+  const int64_t nchunks = cb[(size_t)nb];
   {
     const int64_t target = (int64_t)ctx->num_cu * (ctx->opt_spmv_pb_shares > 0 ? ctx->opt_spmv_pb_shares : 4);
-    const int64_t total = nsteps - hb[0] > 0 ? nsteps - hb[0] : 1;
+    const int64_t total = nchunks > 0 ? nchunks : 1;
     for (int64_t b = 0; b < nb; b++) {
-      const int64_t s0 = hb[(size_t)b], s1 = hb[(size_t)b + 1];
-      if (s1 <= s0) continue;
-      int64_t shares = ((s1 - s0) * target + total / 2) / total;
-      const int64_t most = cdiv(s1 - s0, (int64_t)kPbWaves * 4);  // a wavefront wants at least a batch
-      if (shares > most) shares = most;
+      const int64_t c0 = cb[(size_t)b], c1 = cb[(size_t)b + 1];
+      if (c1 <= c0) continue;
+      int64_t shares = ((c1 - c0) * target + total / 2) / total;
       if (shares < 1) shares = 1;
-      const int64_t nr = shares * kPbWaves;
-      for (int64_t q = 0; q < nr; q++) {
-        wt.push_back(s0 + (int64_t)((__int128)(s1 - s0) * q / nr));
+      if (shares > c1 - c0) shares = c1 - c0;
+      const int64_t per = cdiv(c1 - c0, shares);
+      for (int64_t c = c0; c < c1; c += per) {
+        wt.push_back(c);
+        wt.push_back(c + per < c1 ? c + per : c1);
         wt.push_back(b);
       }
     }
-    wt.push_back(nsteps);
-    wt.push_back(-1);
   }
-  const int64_t nr = (int64_t)wt.size() / 2 - 1;
-  Tmp<int64_t> wtab(ctx);
+  Tmp<int64_t> wtab(ctx), cbase(ctx);
+  Tmp<uint16_t> colc(ctx);
+  Tmp<T> valc(ctx);
+  Tmp<uint32_t> outc(ctx);
   SAMD_TRY(wtab.get((int64_t)wt.size()));
-  SAMD_HIP(ctx, hipMemcpyAsync(wtab.p, wt.data(), sizeof(int64_t) * wt.size(), hipMemcpyHostToDevice, ctx->stream));
-  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // wt is host memory that goes away; the temporaries are released after their use
+  SAMD_TRY(cbase.get(nb + 1));
+  SAMD_TRY(colc.get(nchunks * kPbChunk));
+  SAMD_TRY(valc.get(nchunks * kPbChunk));
+  SAMD_TRY(outc.get(nchunks * (kPbChunk / 32)));
+  SAMD_HIP(ctx, hipMemcpyAsync(cbase.p, cb.data(), sizeof(int64_t) * cb.size(), hipMemcpyHostToDevice, ctx->stream));
+  if (!wt.empty())
+    SAMD_HIP(ctx, hipMemcpyAsync(wtab.p, wt.data(), sizeof(int64_t) * wt.size(), hipMemcpyHostToDevice, ctx->stream));
+  if (nchunks > 0) {
+    hipLaunchKernelGGL((pbf_chunk_kernel<T>), dim3((unsigned)cdiv(nchunks, kBlock / 64)), dim3(kBlock), 0, ctx->stream,
+                       (const int64_t *)bounds.p, (const int64_t *)cbase.p, nb, nchunks, (const uint16_t *)col16.p,
+                       (const T *)pval.p, (const uint32_t *)uout.p, (uint32_t)ototal, colc.p, valc.p, outc.p);
+    SAMD_LAUNCH_CHECK(ctx);
+  }
+  SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // wt and cb are host memory that goes away; the temporaries are released after their use
   a->pb_wtab = wtab.release();
-  a->pb_nwg = nr / kPbWaves;
+  a->pb_nwg = (int64_t)wt.size() / 3;
   a->pb_piece_ptr = bounds.release();
-  a->pb_dgroup = desc.release();
-  a->pb_col16 = colj.release();
+  a->pb_dgroup = outc.release();
+  a->pb_col16 = colc.release();
   a->pb_row16 = row16.release();
-  a->pb_val = valj.release();
+  a->pb_val = valc.release();
   a->pb_prod = prod.release();
   a->pb_fold = 1;
   a->pb_outputs = ototal;
+  if (ctx->logging) fprintf(stderr, "[sparse_amd] two-pass SpMV, folded: %lld entries (padded %lld) -> %lld products\n",
+                            (long long)nnz, (long long)ptotal, (long long)ototal);
   *done = true;
   return 0;
 }
@@ -973,7 +1139,7 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
   const int64_t yslice = PbSlice<T>::kRows;  // rows of y a panel can hold
   int64_t R = ctx->opt_spmv_pb_rows > 0 ? ctx->opt_spmv_pb_rows : yslice;
   int64_t lpb = ctx->opt_spmv_pb_lines > 0 ? ctx->opt_spmv_pb_lines : slice / kPbLine;  // lines per block
-  int64_t E = ctx->opt_spmv_pb_entries > 0 ? ctx->opt_spmv_pb_entries : kPbPanelEntries;
+  int64_t E = ctx->opt_spmv_pb_entries > 0 ? ctx->opt_spmv_pb_entries : kPbPanelEntries;  // (the folded layout's default: below, once `sorted` is known)
   if (R > yslice) R = yslice;
   if (R > 65535) R = 65535;  // 16-bit row offsets
   if (lpb * kPbLine > slice) lpb = slice / kPbLine;
@@ -986,6 +1152,7 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
   // lines sorted into the blocks by popularity (and pass 1 adding up what a row holds in a block) when the popularity
   // is skewed: that is where rows meet the same few blocks again and again
   const bool sorted = ctx->opt_spmv_pb_fold >= 0 && (ctx->opt_spmv_pb_deal > 0 || (ctx->opt_spmv_pb_deal == 0 && vetted && !flat));
+  if (sorted && ctx->opt_spmv_pb_entries <= 0) E = kPbPanelEntriesFolded > a->tile ? kPbPanelEntriesFolded : a->tile;
   if (!force) {
     // the gather has to be the problem: 4-byte values (16 B moved per entry against 8; for 8-byte values the
     // one-pass paths are on par), x beyond the L2s, most tiles spanning a wide column range
@@ -1190,15 +1357,21 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
   if (a->pb_fold) {
     const int lab1 = (int)((ctx->opt_ablate >> 2) & 7);
     const dim3 grid1((unsigned)a->pb_nwg);
-#define SAMD_PB1F(LAB)                                                                                                 \
-  hipLaunchKernelGGL((pb_pass1f_kernel<T, LAB>), grid1, dim3(kPbThreads), 0, ctx->stream, (const int64_t *)a->pb_wtab,  \
-                     (const uint32_t *)a->pb_dgroup, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,               \
-                     (const T *)a->pb_x, a->pb_prod, (int)a->pb_w)
+#define SAMD_PB1F(LAB, WIDE)                                                                                           \
+  hipLaunchKernelGGL((pb_pass1f_kernel<T, LAB, WIDE>), grid1, dim3(kPbThreads), 0, ctx->stream,                        \
+                     (const int64_t *)a->pb_wtab, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,                 \
+                     (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w)
+    // products beyond a 32-bit byte offset (or option ablate bit 30, for the tests): stores through 64-bit addresses
+    const bool wide = (a->pb_outputs + 64) * (int64_t)sizeof(T) >= (int64_t)0x7fffffff || ((ctx->opt_ablate >> 30) & 1);
     if (a->pb_nwg <= 0) {}  // nothing stored
-    else if (lab1 == 1) SAMD_PB1F(1);
-    else if (lab1 == 2) SAMD_PB1F(2);
-    else if (lab1 == 3) SAMD_PB1F(3);
-    else SAMD_PB1F(0);
+    else if (lab1 == 1) SAMD_PB1F(1, false);
+    else if (lab1 == 2) SAMD_PB1F(2, false);
+    else if (lab1 == 3) SAMD_PB1F(3, false);
+    else if (lab1 == 4) SAMD_PB1F(4, false);
+    else if (lab1 == 5) SAMD_PB1F(5, false);
+    else if (lab1 == 6) SAMD_PB1F(6, false);
+    else if (wide) SAMD_PB1F(0, true);
+    else SAMD_PB1F(0, false);
 #undef SAMD_PB1F
   }
   else
