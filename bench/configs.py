@@ -110,9 +110,13 @@ def main():
         torch.cuda.empty_cache()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        M.sr.smvm(A, x)        # the first product builds whatever the record's path needs (once per record)
+        M.sr.smvm(A, x)        # a record's first product runs on what the assembly left (nothing built)
         ctx.sync()
         out["spmv_first_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        t0 = time.perf_counter()
+        M.sr.prepare(A, 1 << 20)   # "many products follow": whatever the record's path needs is built here, once
+        ctx.sync()
+        out["spmv_prepare_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
         ms = timed(lambda: M.sr.smvm(A, x), args.steps, torch)
         # row offsets as the kernel reads them: 2 B (tile-relative u16) on the one-pass stream path of large records
         rb = 2 if (ctx.get_option("spmv_last_path") == 0 and nnz > 4096 * 1024 and not args.algo) else 8
@@ -120,7 +124,9 @@ def main():
         byt = nnz * (vb + ib) + n * rb + n * vb + m * vb
         out.update({"spmv_ms": round(ms, 4), "spmv_GFLOPs": round(2 * nnz / ms / 1e6, 1),
                     "spmv_GBs": round(byt / ms / 1e6, 1), "spmv_frac_peak": round(byt / ms / 1e6 / PEAK, 4)})
+        out["spmv_path_id"] = ctx.get_option("spmv_last_path")
         if ctx.get_option("spmv_last_path") == 3:
+            out["spmv_path"] = "two passes"
             out["pb_fold"] = ctx.get_option("spmv_last_pb_fold")
             out["pb_products"] = ctx.get_option("spmv_last_pb_outputs")
         if args.compare:
@@ -178,6 +184,9 @@ def main():
         elif cfg == "c5r":   # what one of 8 ranks holds after row sharding: an eighth of the rows, every column
             run("C5 row shard 1/8: random 1.25e6 x 1e7, nnz0=1.25e8", "f64", 1250000, 10**7,
                 lambda: synth.random_uniform_coo_device(1250000, 10**7, 125 * 10**6, dev))
+        elif cfg == "c5x":   # SURVEY 8(d)'s stress configuration (n = m = 1e8, ~10 per row) as one of 8 row shards
+            run("C5 stress shard 1/8: random 1.25e7 x 1e8, nnz0=1.25e8", "f64", 12500000, 10**8,
+                lambda: synth.random_uniform_coo_device(12500000, 10**8, 125 * 10**6, dev))
         elif cfg == "c5q":   # kernel lab: few enough panels for one round of resident workgroups
             run("lab: random 5e5 x 1e7, nnz0=5e7", "f64", 500000, 10**7,
                 lambda: synth.random_uniform_coo_device(500000, 10**7, 50 * 10**6, dev))

@@ -173,6 +173,33 @@ def test_c5_row_shard_two_pass_and_column_blocks_against_the_plain_kernel():
     assert float(((y - want).abs() / want.abs()).max()) <= 1e-12
 
 
+def test_c5_stress_shard_against_torch_scatter_add():
+    """SURVEY 8(d)'s stress configuration (n = m = 1e8, about 10 entries per row) as what one of 8 ranks holds
+    after row sharding: uniform random 1.25e7 x 1e8, 1.25e8 triples, f64 -- x is 800 MB, every gather a miss.
+    Assembly: index arrays equal to torch's own sort of the triples; product: within 1e-12 of torch's scatter-add,
+    whatever path the library picks (the test records it)."""
+    torch, ctx = _ctx()
+    from sparse_amd import mk_compressed, synth
+    M = mk_compressed("f64", ctx)
+    n, m = 12500000, 10**8
+    r, c, v = synth.random_uniform_coo_device(n, m, 125 * 10**6, "cuda:0")
+    x = torch.rand(m, device="cuda:0", dtype=torch.float64) + 0.5
+    A = M.sr.sparse(n, m, (r, c, v))
+    want = torch.zeros(n, device="cuda:0", dtype=torch.float64).index_add_(0, r, v * x[c])
+    key = torch.unique(r * m + c)                   # sorted, duplicates merged: the record's (row, column) order
+    ro, ci, va = A.fields()
+    assert A.stored_dims()[2] == key.numel()
+    assert torch.equal(torch.as_tensor(ci, device="cuda:0"), key % m)
+    assert torch.equal(torch.as_tensor(ro, device="cuda:0"), torch.cumsum(torch.bincount(key // m, minlength=n), 0))
+    del key, ro, ci, va, r, c, v
+    y = torch.as_tensor(M.sr.smvm(A, x), device="cuda:0")
+    path = ctx.get_option("spmv_last_path")
+    assert path in (0, 1, 2, 3)
+    nz = want != 0
+    assert float(((y - want).abs()[nz] / want.abs()[nz]).max()) <= 1e-12, "path %d" % path
+    assert bool((y[~nz] == 0).all())
+
+
 def test_c3_hot_column_renumbering_against_the_plain_kernel():
     """configs[2] at scale 22 (same generator and skew as scale 24, a sixteenth of the entries so the module
     stays within a few seconds): the renumbered product is bit-identical to the plain one."""
