@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__r
       if (fold_max > 0 && __ballot(r[u] & kPbFoldFlag) != 0ull)  // a panel of few, heavy rows: fold the runs first
         pb_seg_add<T>(ys, r[u] & (kPbFoldFlag - 1), v[u], lane, fold_max < 64 ? 64 : fold_max);
       else
-        atomicAdd(&ys[r[u] & (kPbFoldFlag - 1)], (acc_t)v[u]);
+        atomicAdd(&ys[lab == 3 ? (((r[u] & (kPbFoldFlag - 1)) & ~31) | (lane & 31)) : (r[u] & (kPbFoldFlag - 1))], (acc_t)v[u]);  // lab 3: every half-wavefront a permutation of the 32 bank pairs (wrong sums)
     }
   };
   int64_t cs = ps + (int64_t)wave * kChunk;
