@@ -12,12 +12,16 @@ python3 - $OUT <<'PY'
 import csv, json, sys, collections, os
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: [0.0, 0])
-kname = None
+# the metric's kernel = the spmv_stream_kernel instantiation launched most often (the timed loop's); the other
+# legs of bench.py launch other instantiations a few times (first products of their records) and are left out
+names = collections.Counter(row["Kernel_Name"].split("(")[0]
+                            for row in csv.DictReader(open(os.path.join(out, "FETCH_SIZE", "p_counter_collection.csv")))
+                            if "spmv_stream_kernel" in row["Kernel_Name"])
+kname = names.most_common(1)[0][0]
 for tag in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum"):
     for row in csv.DictReader(open(os.path.join(out, tag, "p_counter_collection.csv"))):
-        if "spmv_stream_kernel" not in row["Kernel_Name"]:
+        if row["Kernel_Name"].split("(")[0] != kname:
             continue
-        kname = row["Kernel_Name"].split("(")[0]
         a = acc[row["Counter_Name"]]
         a[0] += float(row["Counter_Value"]); a[1] += 1
 m = {k: v[0] / v[1] for k, v in acc.items()}

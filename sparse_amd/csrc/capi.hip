@@ -696,6 +696,7 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "spmv_pb_entries")) ctx->opt_spmv_pb_entries = value;
   else if (!strcmp(key, "spmv_pb_fold")) ctx->opt_spmv_pb_fold = value;
   else if (!strcmp(key, "spmv_pb_oround")) ctx->opt_spmv_pb_oround = value;
+  else if (!strcmp(key, "spmv_pb_xcopy")) ctx->opt_spmv_pb_xcopy = value;
   else if (!strcmp(key, "spmv_pb_shares")) ctx->opt_spmv_pb_shares = value;
   else if (!strcmp(key, "spmv_pb_deal")) ctx->opt_spmv_pb_deal = value;
   else if (!strcmp(key, "ablate")) ctx->opt_ablate = value;

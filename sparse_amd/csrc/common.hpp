@@ -122,6 +122,7 @@ struct futhark_context {
   int64_t opt_spmv_pb = 0;  // two-pass SpMV (spmv_pb.hpp), 0 large skewed gather-bound records of 4-byte values, 1 also flat popularity, 2 always (tests), -1 never
   int64_t opt_spmv_pb_rows = 0, opt_spmv_pb_lines = 0, opt_spmv_pb_entries = 0;  // test overrides: rows per panel,
                                                                                  // 32-column lines per block, entries per panel
+  int64_t opt_spmv_pb_xcopy = 0;  // two-pass SpMV, folded layout: 1 = x copied into block order first (lab / tests), 0 = pass 1 gathers its slices from x
   int64_t opt_spmv_pb_fold = 0;  // two-pass SpMV, products of one row inside one piece summed in pass 1: 0 when it shortens the product stream by >= 15 %, 1 always, -1 never
   int64_t opt_spmv_pb_deal = 0;    // lines into column blocks: 0 sorted by popularity for skewed records (with the folded layout), dealt round otherwise; 1 always sorted; -1 always dealt
   int64_t opt_spmv_pb_shares = 0;  // lab: folded layout, pass 1's workgroups per CU (0 = 4)
@@ -308,6 +309,7 @@ struct CsrBody {
   mutable int64_t *pb_panel_row = nullptr;   // [np + 1] first row of every panel
   mutable int64_t *pb_piece_ptr = nullptr;   // [np * nb + 1] start of every piece, panel-major
   mutable uint32_t *pb_line_of_rank = nullptr;  // [nl] lines by descending entry count
+  mutable uint32_t *pb_line_blk = nullptr;      // folded layout: the same list block by block (pass 1 takes its slices of x through it)
   mutable uint16_t *pb_col16 = nullptr, *pb_row16 = nullptr;  // [nnz] column inside the block, row inside the panel
   mutable T *pb_val = nullptr, *pb_prod = nullptr;            // [nnz] values in piece order; products (rewritten per call)
   mutable uint32_t *pb_dgroup = nullptr;                      // [padded entries / 32] pass 1's destination groups
@@ -343,6 +345,7 @@ inline void csr_release(futhark_context *ctx, CsrBody<T> *b) {
   dfree(ctx, b->pb_panel_row);
   dfree(ctx, b->pb_piece_ptr);
   dfree(ctx, b->pb_line_of_rank);
+  dfree(ctx, b->pb_line_blk);
   dfree(ctx, b->pb_col16);
   dfree(ctx, b->pb_row16);
   dfree(ctx, b->pb_val);

@@ -193,6 +193,14 @@ __global__ __launch_bounds__(kBlock) void pb_dgroup_kernel(const int64_t *__rest
   for (int64_t g = g0; g < g1; g++) dgroup[g] = (uint32_t)(d0 + (g - g0));
 }
 
+// place_line (place q = slot * nb + block) turned block-major: line_blk[block * slots + slot]
+__global__ __launch_bounds__(kBlock) void pb_line_blk_kernel(const uint32_t *__restrict__ place_line, int64_t nq, int64_t nb,
+                                                             uint32_t *__restrict__ line_blk) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nq) return;
+  line_blk[(q % nb) * (nq / nb) + q / nb] = place_line[q];
+}
+
 // x in block order: the line at place q -> block q mod nb, slot q / nb; w = columns per block; nl = places
 template <class T>
 __global__ __launch_bounds__(kBlock) void pb_xperm_kernel(const T *__restrict__ x, int64_t m,
@@ -615,21 +623,17 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
                                                                const uint16_t *__restrict__ colc,
                                                                const T *__restrict__ valc, const T *__restrict__ xperm,
                                                                const uint32_t *__restrict__ outc,
-                                                               T *__restrict__ prod, int w) {
+                                                               T *__restrict__ prod, int w,
+                                                               const uint32_t *__restrict__ line_blk,
+                                                               const T *__restrict__ x, int64_t m) {
   __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
   typedef PbChunkRegs<T> Regs;
   const int64_t s = wtab[3 * (int64_t)blockIdx.x], e = wtab[3 * (int64_t)blockIdx.x + 1], b = wtab[3 * (int64_t)blockIdx.x + 2];
-  {
-    constexpr int PER = 16 / (int)sizeof(T);
-    const raw16 *src = reinterpret_cast<const raw16 *>(xperm + b * (int64_t)w);
-    for (int j = threadIdx.x; j < w / PER; j += kPbThreads) reinterpret_cast<raw16 *>(xs)[j] = src[j];
-  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const PbLane L(lane);
   const int off_c = lane * 16, off_g = (lane >> 5) * 32;
   const __amdgpu_buffer_rsrc_t rprod = pb_rsrc(prod);
-  __syncthreads();
   auto load = [&](int64_t ci, Regs &r) {  // a whole chunk; ci is the same in every lane
     const __amdgpu_buffer_rsrc_t rc = pb_rsrc(colc + ci * kPbChunk), rv = pb_rsrc(valc + ci * kPbChunk),
                                  rg = pb_rsrc(outc + ci * (kPbChunk / 32));
@@ -681,17 +685,50 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
   // the wavefront's chunks: s + wave, s + wave + 16, ...  Requests run two chunks ahead; behind the last chunk the
   // last one is asked for again (it is in cache): behind a branch the compiler cannot tell which requests are
   // outstanding where the paths join, and makes the sums of this chunk wait for the loads of the next ones.
+  // The first two chunks are asked for before the slice of x: both wait for memory, neither for the other.
   const int64_t first = s + wave;
-  if (first < e) {
-    const int nf = (int)((e - first + kPbWaves - 1) / kPbWaves);
-    const int64_t last = first + (int64_t)(nf - 1) * kPbWaves;
-    auto at = [&](int j) {
-      const int64_t ci = first + (int64_t)j * kPbWaves;
-      return ci < last ? ci : last;
-    };
-    Regs ra, rb, rc;
+  const bool any = first < e;
+  const int nf = any ? (int)((e - first + kPbWaves - 1) / kPbWaves) : 0;
+  const int64_t last = first + (int64_t)(nf - 1) * kPbWaves;
+  auto at = [&](int j) {
+    const int64_t ci = first + (int64_t)j * kPbWaves;
+    return ci < last ? ci : last;
+  };
+  Regs ra, rb, rc;
+  if (any) {
     load(at(0), ra);
     load(at(1), rb);
+  }
+  if (line_blk == nullptr) {  // the slice from the copy of x in block order (pb_xperm_kernel: x is not 16-byte aligned)
+    constexpr int PER = 16 / (int)sizeof(T);
+    const raw16 *src = reinterpret_cast<const raw16 *>(xperm + b * (int64_t)w);
+    for (int j = threadIdx.x; j < w / PER; j += kPbThreads) reinterpret_cast<raw16 *>(xs)[j] = src[j];
+  } else {
+    // The slice straight from x, line by line through the block's list of lines (line_blk[b][slot]).  With the lines
+    // sorted into the blocks most blocks have one workgroup, so every line is fetched once, as the copy kernel would
+    // have fetched it, and the copy's 64 MB written and read again drop out (C3: 25 us).  (Round 2 measured this
+    // slower: the blocks were dealt then, four workgroups each fetching every scattered line again.)
+    constexpr int PER = 16 / (int)sizeof(T), PIECES = kPbLine / PER;
+    const uint32_t *tab = line_blk + b * (int64_t)(w / kPbLine);
+    for (int j = threadIdx.x; j < w / PER; j += kPbThreads) {
+      const uint32_t line = tab[j / PIECES];
+      const int64_t c = (int64_t)line * kPbLine + (j % PIECES) * PER;
+      raw16 v = raw16{0u, 0u, 0u, 0u};
+      if (line != 0xffffffffu) {
+        if (c + PER <= m) {
+          v = *reinterpret_cast<const raw16 *>(x + c);
+        } else {
+          T t[PER];
+#pragma unroll
+          for (int u = 0; u < PER; u++) t[u] = c + u < m ? x[c + u] : (T)0;
+          v = *reinterpret_cast<const raw16 *>(t);
+        }
+      }
+      reinterpret_cast<raw16 *>(xs)[j] = v;
+    }
+  }
+  __syncthreads();
+  if (any) {
     for (int j = 0;;) {
       load(at(j + 2), rc);
       work(ra);
@@ -1330,6 +1367,14 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
     a->pb_prod = prod.release();
     a->pb_outputs = ptotal;
   }
+  if (a->pb_fold) {  // the same list block by block, for pass 1's slice loads
+    Tmp<uint32_t> line_blk(ctx);
+    SAMD_TRY(line_blk.get(nq));
+    hipLaunchKernelGGL(pb_line_blk_kernel, dim3((unsigned)cdiv(nq, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const uint32_t *)line_of_rank.p, nq, nb, line_blk.p);
+    SAMD_LAUNCH_CHECK(ctx);
+    a->pb_line_blk = line_blk.release();
+  }
   a->pb_line_of_rank = line_of_rank.release();
   a->pb_x = xperm.release();
   a->pb_state = 1;
@@ -1340,7 +1385,10 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
 
 template <class T>
 int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
-  if (((uintptr_t)x & 15) == 0)
+  // folded layout, x 16-byte aligned: pass 1 takes its slices from x itself
+  const bool gather = a->pb_fold && a->pb_line_blk != nullptr && ((uintptr_t)x & 15) == 0 && ctx->opt_spmv_pb_xcopy <= 0;
+  if (gather) {}
+  else if (((uintptr_t)x & 15) == 0)
     hipLaunchKernelGGL((pb_xperm_vec_kernel<T>), dim3((unsigned)cdiv(a->pb_nl * (kPbLine * (int64_t)sizeof(T) / 16), kBlock)),
                        dim3(kBlock), 0, ctx->stream, x, a->m, (const uint32_t *)a->pb_line_of_rank, a->pb_nl, a->pb_nb, a->pb_w,
                        a->pb_x);
@@ -1360,7 +1408,8 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
 #define SAMD_PB1F(LAB, WIDE)                                                                                           \
   hipLaunchKernelGGL((pb_pass1f_kernel<T, LAB, WIDE>), grid1, dim3(kPbThreads), 0, ctx->stream,                        \
                      (const int64_t *)a->pb_wtab, (const uint16_t *)a->pb_col16, (const T *)a->pb_val,                 \
-                     (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w)
+                     (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w,                     \
+                     gather ? (const uint32_t *)a->pb_line_blk : (const uint32_t *)nullptr, x, a->m)
     // products beyond a 32-bit byte offset (or option ablate bit 30, for the tests): stores through 64-bit addresses
     const bool wide = (a->pb_outputs + 64) * (int64_t)sizeof(T) >= (int64_t)0x7fffffff || ((ctx->opt_ablate >> 30) & 1);
     if (a->pb_nwg <= 0) {}  // nothing stored

@@ -461,9 +461,12 @@ def test_smvm_two_pass_panels(ctx, dtype, geom, fold):
             assert ctx.get_option("spmv_last_path") == 3 and ctx.get_option("spmv_last_pb_fold") == (fold > 0)
             x2 = synth.uniform_values(6, m, dtype)
             close(M.sr.smvm(A, x2), O.sr_smvm(Ao, x2), dtype)
+            ctx.set_option("spmv_pb_xcopy", 1)          # x copied into block order first (what an x that is not
+            close(M.sr.smvm(A, x2), O.sr_smvm(Ao, x2), dtype)   # 16-byte aligned gets) instead of gathered by pass 1
+            ctx.set_option("spmv_pb_xcopy", 0)
             assert_same_record(A, Ao)
     finally:
-        for k in ("spmv_pb", "spmv_pb_rows", "spmv_pb_lines", "spmv_pb_entries", "spmv_pb_fold", "spmv_pb_deal"):
+        for k in ("spmv_pb", "spmv_pb_rows", "spmv_pb_lines", "spmv_pb_entries", "spmv_pb_fold", "spmv_pb_deal", "spmv_pb_xcopy"):
             ctx.set_option(k, 0)
 
 
