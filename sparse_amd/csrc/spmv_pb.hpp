@@ -50,7 +50,8 @@ namespace samd {
 constexpr int kPbThreads = 1024;  // one workgroup per CU: the slice takes most of the CU's 160 KB of LDS
 constexpr int kPbWaves = kPbThreads / 64;
 constexpr int kPbLine = 32;                         // columns per line (the unit dealt to blocks)
-constexpr int kPbSliceBytes = 128 << 10;            // slice of x (pass 1) or y (pass 2) in LDS
+constexpr int kPbSliceBytes = 128 << 10;            // slice of y (pass 2) in LDS (f64 accumulators: 16 K rows)
+constexpr int kPbXSliceBytes = 160 << 10;           // slice of x (pass 1) in LDS: all of it (f32: 40 K columns per block)
 constexpr int64_t kPbPanelEntries = 256 << 10;      // a panel is closed once it holds this many entries (measured on C3:
                                                     // 1 M 1.22 ms, 512 K 0.96, 256 K 0.94, 128 K 0.99, 64 K 1.27 in pass 2)
 constexpr int kPbFoldMax = 16;                      // pass 2 folds a wavefront's runs when it holds at most this many (C3: 2: 0.95 ms, 8: 0.91, 16: 0.89, 32: 0.93, 48: 1.01)
@@ -58,6 +59,7 @@ constexpr int64_t kPbMinBytes = 16 << 20;            // x at least this large (R
                                                     // scale 20 0.21 / 0.15, 21 0.264 / 0.259, 22 0.47 / 0.51, 23 0.81 / 1.01, 24 1.62 / 2.08)
 constexpr int kPbFoldRows = 64;                     // a panel of fewer rows than this keeps its entries sorted by row: pass 2 folds runs
 constexpr int kPbFoldFlag = 0x8000;                 // row16 bit that says so
+constexpr int kPbHeadFlag = 0x8000;                 // folded layout, while it is built: bit of the entry's row that says it starts a run
 constexpr int kPbRunCap = 32;                       // folded layout: a run is cut at every multiple of this many positions (C3, 16 -- runs inside one DPP row, one scan step fewer: pass 1 the same 0.557 ms, 7 % more products, pass 2 0.160 -> 0.184)
 constexpr int kPbOutRound = 8;                      // folded layout: a piece's outputs start at a multiple of this many products (C3, round 3, chunked layout, 32 / 16 / 8: pass 1 0.504 / 0.501 / 0.498 ms, pass 2 0.158 / 0.155 / 0.1545, 95.7 / 89.0 / 86.1 M products; round 2's kernel liked 32: 1 / 8 / 16 / 32 gave pass 1 0.714 / 0.707 / 0.694 / 0.687)
 constexpr int64_t kPbPanelEntriesFolded = 512 << 10; // the same for the folded layout, whose pass 2 sees a third of the entries (C3, 256 K / 512 K / 1 M: pass 1 0.521 / 0.504 / 0.501 ms, pass 2 0.160 / 0.162 / 0.165, 100.6 / 95.7 / 93.7 M products)
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1_kernel(const int64_t *__r
                                                               const T *__restrict__ pval, const T *__restrict__ xperm,
                                                               const uint32_t *__restrict__ dgroup,
                                                               T *__restrict__ prod, int w, int lab) {
-  __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
+  __shared__ __attribute__((aligned(16))) T xs[kPbXSliceBytes / sizeof(T)];
   const int64_t b = blockIdx.x;
   // (tried: the slice straight from x through line_of_rank, no renumbered copy -- the scattered 128-byte lines in
   // front of the stream cost pass 1 0.11 ms where the separate copy kernel costs 0.06)
@@ -588,7 +590,10 @@ __device__ __forceinline__ T pb_run_sum32(T p, bool all_heads, uint32_t h, const
 // entry u * 64 + l (u = 0 .. 7: the u-th instruction's lane l) stored so that a lane's eight entries are neighbours:
 //   colc[ci * 512 + l * 8 + u]                                    one 16-byte load per lane and chunk
 //   valc[ci * 512 + (u / P) * 64 P + l * P + u % P], P = 16 / sizeof(T)   8 / P 16-byte loads, each one contiguous KiB
-//   outc[ci * 16 + h * 8 + u]                                     first output of half h (lanes 32 h ..) of instruction u
+//   outc[ci * 32 + h * 8 + u]                                     first output of half h (lanes 32 h ..) of instruction u
+//   outc[ci * 32 + 16 + h * 8 + u]                                the run starts among that half's 32 lanes, as a mask
+// (the masks ready-made: no ballot in the loop, and all 16 bits of a column are the column, so a block can be as
+// wide as the whole LDS holds: 40 K columns of f32)
 // Why: with one workgroup per CU (the slice of x takes the LDS) a CU has 16 wavefronts to keep its share of the HBM
 // stream in flight, and a wavefront that asks for a step as 8 + 8 + 8 two- and four-byte loads cannot have more than
 // two steps outstanding (the 6-bit counter of outstanding vector-memory instructions also counts the 8 stores of a
@@ -599,9 +604,9 @@ constexpr int kPbChunk = 512;  // entries per chunk: 8 per lane
 template <class T>
 struct PbChunkRegs {
   static constexpr int kPer = 16 / (int)sizeof(T), kVecs = 8 / kPer;
-  pb_u32x4 c, v[kVecs], g[2];
-  __device__ __forceinline__ uint32_t col(int u) const { return (u & 1) ? (c[u >> 1] >> 16) & 0x7fffu : c[u >> 1] & 0x7fffu; }
-  __device__ __forceinline__ bool head(int u) const { return (c[u >> 1] & ((u & 1) ? 0x80000000u : 0x8000u)) != 0; }
+  pb_u32x4 c, v[kVecs], g[2], h[2];
+  __device__ __forceinline__ uint32_t col(int u) const { return (u & 1) ? c[u >> 1] >> 16 : c[u >> 1] & 0xffffu; }
+  __device__ __forceinline__ uint32_t heads(int u) const { return h[u >> 2][u & 3]; }  // run starts among the 32 lanes of this lane's half
   __device__ __forceinline__ uint32_t out(int u) const { return g[u >> 2][u & 3]; }
   __device__ __forceinline__ T val(int u) const {
     if constexpr (sizeof(T) == 4) {
@@ -626,7 +631,7 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
                                                                T *__restrict__ prod, int w,
                                                                const uint32_t *__restrict__ line_blk,
                                                                const T *__restrict__ x, int64_t m) {
-  __shared__ __attribute__((aligned(16))) T xs[kPbSliceBytes / sizeof(T)];
+  __shared__ __attribute__((aligned(16))) T xs[kPbXSliceBytes / sizeof(T)];
   typedef PbChunkRegs<T> Regs;
   const int64_t s = wtab[3 * (int64_t)blockIdx.x], e = wtab[3 * (int64_t)blockIdx.x + 1], b = wtab[3 * (int64_t)blockIdx.x + 2];
   const int lane = threadIdx.x & 63;
@@ -636,12 +641,14 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
   const __amdgpu_buffer_rsrc_t rprod = pb_rsrc(prod);
   auto load = [&](int64_t ci, Regs &r) {  // a whole chunk; ci is the same in every lane
     const __amdgpu_buffer_rsrc_t rc = pb_rsrc(colc + ci * kPbChunk), rv = pb_rsrc(valc + ci * kPbChunk),
-                                 rg = pb_rsrc(outc + ci * (kPbChunk / 32));
+                                 rg = pb_rsrc(outc + ci * (kPbChunk / 16));
     r.c = __builtin_amdgcn_raw_buffer_load_b128(rc, off_c, 0, 2);  // aux 2: non-temporal
 #pragma unroll
     for (int q = 0; q < Regs::kVecs; q++) r.v[q] = __builtin_amdgcn_raw_buffer_load_b128(rv, off_c + q * 1024, 0, 2);
     r.g[0] = __builtin_amdgcn_raw_buffer_load_b128(rg, off_g, 0, 0);
     r.g[1] = __builtin_amdgcn_raw_buffer_load_b128(rg, off_g + 16, 0, 0);
+    r.h[0] = __builtin_amdgcn_raw_buffer_load_b128(rg, off_g + 64, 0, 0);
+    r.h[1] = __builtin_amdgcn_raw_buffer_load_b128(rg, off_g + 80, 0, 0);
   };
   // The sums are stored where they fall, a group's few at a time: short, unaligned pieces of lines, which the memory
   // system charges per piece rather than per byte (C3, lines sorted into the blocks: 84 M sums = 0.34 GB cost 0.16 ms
@@ -657,12 +664,8 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
     for (int u = 0; u < 8; u++) pr[u] = LAB == 2 ? r.val(u) : (T)(r.val(u) * xs[r.col(u)]);
 #pragma unroll
     for (int u = 0; u < 8; u++) {
-      const unsigned long long heads = __ballot(r.head(u));
-      // this lane's half of the mask, picked from two scalars (bits 0 and 32 are always set: lanes 0 and 32 start a run)
-      const uint32_t hlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)heads);
-      const uint32_t hhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(heads >> 32));
-      const uint32_t h = L.hi ? hhi : hlo;
-      const T sum = (LAB == 4 || LAB == 5) ? pr[u] : pb_run_sum32<T>(pr[u], heads == ~0ull, h, L);
+      const uint32_t h = r.heads(u);  // this lane's half of the mask (bit 0 is always set: lanes 0 and 32 start a run)
+      const T sum = (LAB == 4 || LAB == 5) ? pr[u] : pb_run_sum32<T>(pr[u], __ballot(h != 0xffffffffu) == 0ull, h, L);
       const uint32_t tails = (h >> 1) | 0x80000000u;  // a run ends where the next lane starts one, and at the end of its half
       if (LAB == 6) {  // lab: three whole-wavefront stores per chunk (about the same bytes as the eight partial ones)
         if (u < 3) pb_bstore<0>(sum, rprod, (int)((r.out(u) + (uint32_t)L.l5) * (uint32_t)sizeof(T)));
@@ -749,8 +752,9 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass1f_kernel(const int64_t *__
 template <class T>
 __global__ __launch_bounds__(kBlock) void pbf_chunk_kernel(const int64_t *__restrict__ bounds, const int64_t *__restrict__ cbase,
                                                            int64_t nb, int64_t nchunks, const uint16_t *__restrict__ col16,
-                                                           const T *__restrict__ pval, const uint32_t *__restrict__ uout,
-                                                           uint32_t trash, uint16_t *__restrict__ colc, T *__restrict__ valc,
+                                                           const uint16_t *__restrict__ rowt, const T *__restrict__ pval,
+                                                           const uint32_t *__restrict__ uout, uint32_t trash,
+                                                           uint16_t *__restrict__ colc, T *__restrict__ valc,
                                                            uint32_t *__restrict__ outc) {
   constexpr int kPer = 16 / (int)sizeof(T);
   const int64_t ci = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -766,16 +770,22 @@ __global__ __launch_bounds__(kBlock) void pbf_chunk_kernel(const int64_t *__rest
   const int n = left < kPbChunk ? (int)left : kPbChunk;
   uint16_t *cd = colc + ci * kPbChunk + lane * 8;
   T *vd = valc + ci * kPbChunk;
+  uint32_t *od = outc + ci * (kPbChunk / 16);
 #pragma unroll
   for (int u = 0; u < 8; u++) {
     const int o = u * 64 + lane;
     const bool ok = o < n;
-    cd[u] = ok ? col16[ls + o] : (uint16_t)0x8000;
+    cd[u] = ok ? col16[ls + o] : (uint16_t)0;
     vd[(u / kPer) * (64 * kPer) + lane * kPer + u % kPer] = ok ? pval[ls + o] : (T)0;
+    const unsigned long long heads = __ballot(!ok || (rowt[ls + o] & kPbHeadFlag) != 0);  // pads behind the block: a run each
+    if (lane == 0) {
+      od[16 + u] = (uint32_t)heads;
+      od[16 + 8 + u] = (uint32_t)(heads >> 32);
+    }
   }
   if (lane < kPbChunk / 32) {
     const int k = 2 * (lane & 7) + (lane >> 3);  // group of instruction u = lane & 7, half lane >> 3
-    outc[ci * (kPbChunk / 32) + lane] = k * 32 < n ? uout[(ls >> 5) + k] : trash;
+    od[lane] = k * 32 < n ? uout[(ls >> 5) + k] : trash;
   }
 }
 
@@ -890,9 +900,9 @@ __global__ __launch_bounds__(kBlock) void pbf_place_kernel(const int32_t *__rest
   const int32_t c = col[src];
   const int64_t q = rank_of_line[c / kPbLine];
   const bool head = i == (int64_t)i0 || (pos & (kPbRunCap - 1)) == 0;
-  col16[pos] = (uint16_t)(((q / nb) * kPbLine + (c % kPbLine)) | (head ? 0x8000 : 0));
+  col16[pos] = (uint16_t)((q / nb) * kPbLine + (c % kPbLine));
   pval[pos] = val[src];
-  rowt[pos] = rr[i];
+  rowt[pos] = (uint16_t)(rr[i] | (head ? kPbHeadFlag : 0));
 }
 
 // per piece: its first pad starts the trash run; heads per group counted afterwards
@@ -900,22 +910,22 @@ __global__ __launch_bounds__(kBlock) void pbf_padhead_kernel(const int64_t *__re
                                                              const uint32_t *__restrict__ piece_run,
                                                              const uint32_t *__restrict__ piece_long,
                                                              const int64_t *__restrict__ sbase,
-                                                             const int64_t *__restrict__ spos, int64_t pieces,
-                                                             uint16_t *__restrict__ col16) {
+                                                             const int64_t *__restrict__ spos, int64_t pieces, int trash_row,
+                                                             uint16_t *__restrict__ rowt) {
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= pieces) return;
   if (((piece_ptr[k + 1] - piece_ptr[k]) & 31) == 0) return;
   const int64_t all = (int64_t)piece_run[k + 1] - (int64_t)piece_run[k], longs = (int64_t)piece_long[k];
-  col16[spos[sbase[k] + ((longs + 31) & ~(int64_t)31) + (((all - longs) + 31) & ~(int64_t)31)]] = 0x8000;
+  rowt[spos[sbase[k] + ((longs + 31) & ~(int64_t)31) + (((all - longs) + 31) & ~(int64_t)31)]] = (uint16_t)(trash_row | kPbHeadFlag);
 }
 
-__global__ __launch_bounds__(kBlock) void pbf_group_heads_kernel(const uint16_t *__restrict__ col16, int64_t groups,
+__global__ __launch_bounds__(kBlock) void pbf_group_heads_kernel(const uint16_t *__restrict__ rowt, int64_t groups,
                                                                  uint32_t *__restrict__ cnt) {
   const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (g > groups) return;
   uint32_t n = 0;
   if (g < groups) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(col16 + g * 32);
+    const uint4 *p = reinterpret_cast<const uint4 *>(rowt + g * 32);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const uint4 w = p[q];
@@ -963,15 +973,14 @@ __global__ __launch_bounds__(kBlock) void pbf_uout_kernel(const int64_t *__restr
 }
 
 // the row of every output, where pass 2 streams it
-__global__ __launch_bounds__(kBlock) void pbf_rows_out_kernel(const uint16_t *__restrict__ col16,
-                                                              const uint16_t *__restrict__ rowt, int64_t ptotal,
+__global__ __launch_bounds__(kBlock) void pbf_rows_out_kernel(const uint16_t *__restrict__ rowt, int64_t ptotal,
                                                               const uint32_t *__restrict__ uout,
                                                               uint16_t *__restrict__ row16) {
   const int64_t pos = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // ptotal is a multiple of 32, blocks of 256
   const bool ok = pos < ptotal;
-  const bool head = ok && (col16[pos] & 0x8000) != 0;
+  const bool head = ok && (rowt[pos] & kPbHeadFlag) != 0;
   const unsigned long long heads = __ballot(head);
-  if (head) row16[(int64_t)uout[pos >> 5] + pb_rank_in_half(heads, (int)(threadIdx.x & 63))] = rowt[pos];
+  if (head) row16[(int64_t)uout[pos >> 5] + pb_rank_in_half(heads, (int)(threadIdx.x & 63))] = (uint16_t)(rowt[pos] & (kPbHeadFlag - 1));
 }
 
 __global__ __launch_bounds__(kBlock) void pbf_bounds_kernel(const int64_t *__restrict__ sbase, const int64_t *__restrict__ spos,
@@ -1066,10 +1075,10 @@ int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, co
   SAMD_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(pbf_padhead_kernel, dim3(pgrid), dim3(kBlock), 0, ctx->stream, piece_ptr, (const uint32_t *)piece_run.p,
                      (const uint32_t *)piece_long.p,
-                     (const int64_t *)sbase.p, (const int64_t *)spos.p, pieces, col16.p);
+                     (const int64_t *)sbase.p, (const int64_t *)spos.p, pieces, (int)PbSlice<T>::kRows, rowt.p);
   SAMD_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(pbf_group_heads_kernel, dim3((unsigned)cdiv(groups + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
-                     (const uint16_t *)col16.p, groups, hx.p);
+                     (const uint16_t *)rowt.p, groups, hx.p);
   SAMD_LAUNCH_CHECK(ctx);
   SAMD_TRY((device_scan<uint32_t, OpAdd, PtrIn<uint32_t>, true>(ctx, PtrIn<uint32_t>{hx.p}, groups + 1, 0u, OpAdd(), hx.p,
                                                                  (uint32_t *)nullptr)));
@@ -1093,7 +1102,7 @@ int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, co
                      (const int64_t *)spos.p, (const uint32_t *)hx.p, (const int64_t *)poff.p, pieces, np, nb, uout.p);
   SAMD_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(pbf_rows_out_kernel, dim3((unsigned)cdiv(ptotal, kBlock)), dim3(kBlock), 0, ctx->stream,
-                     (const uint16_t *)col16.p, (const uint16_t *)rowt.p, ptotal, (const uint32_t *)uout.p, row16.p);
+                     (const uint16_t *)rowt.p, ptotal, (const uint32_t *)uout.p, row16.p);
   SAMD_LAUNCH_CHECK(ctx);
   hipLaunchKernelGGL(pbf_bounds_kernel, dim3((unsigned)cdiv(nb + 1 + np + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                      (const int64_t *)sbase.p, (const int64_t *)spos.p, (const int64_t *)poff.p, np, nb, bounds.p);
@@ -1134,14 +1143,15 @@ int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, co
   SAMD_TRY(cbase.get(nb + 1));
   SAMD_TRY(colc.get(nchunks * kPbChunk));
   SAMD_TRY(valc.get(nchunks * kPbChunk));
-  SAMD_TRY(outc.get(nchunks * (kPbChunk / 32)));
+  SAMD_TRY(outc.get(nchunks * (kPbChunk / 16)));
   SAMD_HIP(ctx, hipMemcpyAsync(cbase.p, cb.data(), sizeof(int64_t) * cb.size(), hipMemcpyHostToDevice, ctx->stream));
   if (!wt.empty())
     SAMD_HIP(ctx, hipMemcpyAsync(wtab.p, wt.data(), sizeof(int64_t) * wt.size(), hipMemcpyHostToDevice, ctx->stream));
   if (nchunks > 0) {
     hipLaunchKernelGGL((pbf_chunk_kernel<T>), dim3((unsigned)cdiv(nchunks, kBlock / 64)), dim3(kBlock), 0, ctx->stream,
                        (const int64_t *)bounds.p, (const int64_t *)cbase.p, nb, nchunks, (const uint16_t *)col16.p,
-                       (const T *)pval.p, (const uint32_t *)uout.p, (uint32_t)ototal, colc.p, valc.p, outc.p);
+                       (const uint16_t *)rowt.p, (const T *)pval.p, (const uint32_t *)uout.p, (uint32_t)ototal, colc.p, valc.p,
+                       outc.p);
     SAMD_LAUNCH_CHECK(ctx);
   }
   SAMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // wt and cb are host memory that goes away; the temporaries are released after their use
@@ -1172,7 +1182,7 @@ int pb_prepare(futhark_context *ctx, const CsrBody<T> *a, bool vetted, bool flat
   if (!a->col32 || a->nnz == 0 || a->n == 0 || a->tile <= 0) return 0;
   const bool force = ctx->opt_spmv_pb > 1;
   // slice sizes (overridable for tests so that small records have many panels and blocks)
-  const int64_t slice = kPbSliceBytes / (int64_t)sizeof(T);
+  const int64_t slice = kPbXSliceBytes / (int64_t)sizeof(T);
   const int64_t yslice = PbSlice<T>::kRows;  // rows of y a panel can hold
   int64_t R = ctx->opt_spmv_pb_rows > 0 ? ctx->opt_spmv_pb_rows : yslice;
   int64_t lpb = ctx->opt_spmv_pb_lines > 0 ? ctx->opt_spmv_pb_lines : slice / kPbLine;  // lines per block
