@@ -177,6 +177,9 @@ def c3_leg(args, torch, dev, ctx):
         M.sr.smvm_into(yh, A, xh)
     ts = per_step_ms(torch, lambda: M.sr.smvm_into(yh, A, xh), steps)
     ms, med = sum(ts) / len(ts), median(ts)
+    for _ in range(LEG_SETTLE):                     # the same again on a card that has been at it for ~0.15 s
+        M.sr.smvm_into(yh, A, xh)
+    med_settled = median(per_step_ms(torch, lambda: M.sr.smvm_into(yh, A, xh), steps))
     byt = nnz * (4 + 4) + n * 8 + n * 4 + n * 4     # entries (f32 value + i32 column) + row offsets + y + x
     out = {"workload": "COO->CSR assembly + SpMV, RMAT scale %d, edge factor 18, f32 (BASELINE configs[2])" % args.c3_scale,
            "nnz0": nnz0, "nnz": nnz, "assembly_ms": round(asm_ms, 3), "assembly_Mtriples_per_s": round(nnz0 / asm_ms / 1e3, 1),
@@ -185,6 +188,10 @@ def c3_leg(args, torch, dev, ctx):
            "GFLOPs": round(2.0 * nnz / med / 1e6, 1), "algorithmic_bytes": byt,
            "achieved_GBs": round(byt / med / 1e6, 1), "frac": round(byt / med / 1e6 / HBM_PEAK_GBS, 4),
            "frac_of_mean": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4),
+           "products_before_timed_region": 5,
+           "settled": {"ms_per_step_median": round(med_settled, 4), "frac": round(byt / med_settled / 1e6 / HBM_PEAK_GBS, 4),
+                       "preceded_by_products": 5 + steps + LEG_SETTLE,
+                       "note": "the same steps timed again after %d more products" % LEG_SETTLE},
            "spmv_path": SPMV_PATHS.get(path, str(path)), "pb_fold": ctx.get_option("spmv_last_pb_fold"),
            "first_product_ms_nothing_built": round(first_ms, 3), "first_product_path": SPMV_PATHS.get(first_path, str(first_path)),
            "prepare_ms": round(prep_ms, 2),
@@ -226,6 +233,9 @@ def c4_leg(args, torch, dev, ctx):
         M.sr.smm(A, Bh)
     ts = per_step_ms(torch, lambda: M.sr.smm(A, Bh), steps)
     ms, med = sum(ts) / len(ts), median(ts)
+    for _ in range(LEG_SETTLE):
+        M.sr.smm(A, Bh)
+    med_settled = median(per_step_ms(torch, lambda: M.sr.smm(A, Bh), steps))
     byt = nnz * (8 + 4) + n * 8 + (n + n) * k * 8
     # the ceiling of this kernel's own mix: per 1024-entry tile 12 KB of entries + the tile's share of B in, of C out
     tiles = (nnz + 1023) // 1024
@@ -240,6 +250,10 @@ def c4_leg(args, torch, dev, ctx):
            "mix_ceiling": {"us": round(us, 1), "GBs": round(gbs, 1), "read_bytes_per_tile": rd, "write_bytes_per_tile": wr, "tiles": tiles,
                            "note": "the same bytes per tile streamed in and out with no arithmetic (measure_bandwidth)"},
            "frac_of_mix_ceiling": round(us / 1e3 / med, 4),
+           "products_before_timed_region": 4,
+           "settled": {"ms_per_step_median": round(med_settled, 4), "frac": round(byt / med_settled / 1e6 / HBM_PEAK_GBS, 4),
+                       "frac_of_mix_ceiling": round(us / 1e3 / med_settled, 4), "preceded_by_products": 4 + steps + LEG_SETTLE,
+                       "note": "the same steps timed again after %d more products" % LEG_SETTLE},
            "parity": "columns 0, 31, 63 of C within 1e-12 of smvm on those columns of B (max rel %.2g)" % rel}
     del A, B, Bh
     ctx.clear_caches()
@@ -259,6 +273,7 @@ def max_over_ranks(torch, dist, dev, v):
 
 
 SETTLE = 300   # products of the reproducibility gate (about 60 ms on the C2 workload)
+LEG_SETTLE = 250   # products between the first and the second timing of the c3 / c4 legs
 
 
 def c5_leg(args, torch, dist, world, rank, dev, ctx, M):
