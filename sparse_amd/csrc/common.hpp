@@ -123,7 +123,7 @@ struct futhark_context {
   int64_t opt_spmv_pb_rows = 0, opt_spmv_pb_lines = 0, opt_spmv_pb_entries = 0;  // test overrides: rows per panel,
                                                                                  // 32-column lines per block, entries per panel
   int64_t opt_spmv_pb_xcopy = 0;  // two-pass SpMV, folded layout: 1 = x copied into block order first (lab / tests), 0 = pass 1 gathers its slices from x
-  int64_t opt_spmv_pb_fold = 0;  // two-pass SpMV, products of one row inside one piece summed in pass 1: 0 when it shortens the product stream by >= 15 %, 1 always, -1 never
+  int64_t opt_spmv_pb_fold = 0;  // two-pass SpMV, products of one row inside one piece summed in pass 1: 0 and 1 always (round 3: it wins whatever folds), -1 never
   int64_t opt_spmv_pb_deal = 0;    // lines into column blocks: 0 sorted by popularity for skewed records (with the folded layout), dealt round otherwise; 1 always sorted; -1 always dealt
   int64_t opt_spmv_pb_shares = 0;  // lab: folded layout, pass 1's workgroups per CU (0 = 4)
   int64_t opt_spmv_pb_oround = 0;  // lab: folded layout, alignment of a piece's outputs in products (0 = kPbOutRound)

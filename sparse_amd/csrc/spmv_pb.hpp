@@ -1016,9 +1016,10 @@ int pbf_build(futhark_context *ctx, const CsrBody<T> *a, const uint32_t *eks, co
   if (ctx->logging) fprintf(stderr, "[sparse_amd] two-pass SpMV: %lld runs for %lld entries\n", (long long)runs, (long long)nnz);
   // not worth the fold arithmetic?  (With sorted blocks there is no other layout: the plain pass 1 splits every block
   // into the same number of shares.)
-  // (Round 3: the folded layout's pass 1 reads wide and gathers x itself, so it pays from 5 % fewer products on --
-  // measured on the C5 shard, 9 % fewer: 0.760 -> 0.729 ms; before, the threshold was 15 %.)
-  if (!sorted && ctx->opt_spmv_pb_fold <= 0 && (double)runs > 0.95 * (double)nnz) return 0;
+  // (Round 2 declined below 15 % fewer products.  Round 3's pass 1 reads wide and gathers x itself: measured
+  // against the plain layout it wins whatever folds -- C5 whole, 8.5 % fewer products: 5.84 -> 5.10 ms; its shard
+  // 0.760 -> 0.725; 12.5 entries per row, 1 % fewer: 0.884 -> 0.867 -- so the plain layout is what option
+  // spmv_pb_fold = -1 and the 32-bit limits below fall back to.)
   if (runs + 65 * pieces >= (int64_t)0xffffff00LL) return 0;                      // 32-bit places and outputs
   Tmp<uint32_t> run_start(ctx), piece_run(ctx), run_slot(ctx), len(ctx);
   Tmp<int64_t> sbase(ctx), spos(ctx);
