@@ -427,6 +427,95 @@ __global__ __launch_bounds__(kPbThreads) void pb_pass2_kernel(const int64_t *__r
   for (int j2 = tid; j2 < rows; j2 += kPbThreads) y[r0 + j2] = (T)ys[j2];
 }
 
+typedef unsigned int pb_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int pb_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPbRsrcFlags = 0x00020000;  // gfx9 raw buffer, 32-bit data format
+
+// a raw buffer (stride 0) over `bytes` bytes from base: offsets behind them read as zeros and are not stored
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pb_rsrc(const void *base, int bytes = 0x7ffffffe) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, kPbRsrcFlags);
+}
+
+// ---- pass 2 of the folded layout, two products per lane.  A group of 16 lanes then adds products 2 l and, in a
+// second instruction, 2 l + 1 of 32 NEIGHBOURING products: half of one dealt group of 32, whose rows all differ in
+// row mod 32, so the bank deal holds as it stands -- with one 4-byte load of rows and one load of sums per 128
+// products instead of two of each.  (Four per lane, the stream stored transposed inside every 64 so that the deal
+// still holds: pass 2 0.145 -> 0.138 ms on C3, but pass 1's stores, strided inside their 256 bytes, 0.521 -> 0.547.)
+// The panel's stream is a multiple of 64 products long (pbf_panel_align_kernel); the places behind it are out of
+// the buffers' range: row 0, sum 0.
+template <class T>
+__global__ __launch_bounds__(kPbThreads) void pb_pass2p_kernel(const int64_t *__restrict__ panel_ptr,
+                                                               const int64_t *__restrict__ panel_row,
+                                                               const uint16_t *__restrict__ row16,
+                                                               const T *__restrict__ prod, T *__restrict__ y, int lab) {
+  typedef typename PbAcc<T>::type acc_t;
+  constexpr int kTrash = PbSlice<T>::kRows;
+  constexpr int S = 4, kStep = 128;  // loads per batch, products per load
+  __shared__ acc_t ys[kTrash + 32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int64_t p = blockIdx.x;
+  const int64_t r0 = panel_row[p];
+  const int rows = (int)(panel_row[p + 1] - r0);
+  for (int j = tid; j < rows; j += kPbThreads) ys[j] = (acc_t)0;
+  __syncthreads();
+  const int64_t ps = panel_ptr[p], pe = panel_ptr[p + 1];
+  struct Regs {
+    uint32_t r[S];
+    T v[S][2];
+  };
+  auto load = [&](int64_t cs, Regs &g) {  // cs may lie behind the end: nothing is asked for then
+    const int64_t left = pe - cs;
+    const int n = left <= 0 ? 0 : left < S * kStep ? (int)left : S * kStep;
+    const int64_t at = left > 0 ? cs : ps;
+    const __amdgpu_buffer_rsrc_t rr = pb_rsrc(row16 + at, n * 2), rv = pb_rsrc(prod + at, n * (int)sizeof(T));
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      g.r[s] = __builtin_amdgcn_raw_buffer_load_b32(rr, lane * 4 + s * (kStep * 2), 0, 2);
+      if constexpr (sizeof(T) == 4) {
+        const pb_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rv, lane * 8 + s * (kStep * 4), 0, 2);
+        const uint32_t w0 = w[0], w1 = w[1];
+        g.v[s][0] = __builtin_bit_cast(T, w0);
+        g.v[s][1] = __builtin_bit_cast(T, w1);
+      } else {
+        const pb_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rv, lane * 16 + s * (kStep * 8), 0, 2);
+        const uint64_t w0 = ((uint64_t)w[1] << 32) | w[0], w1 = ((uint64_t)w[3] << 32) | w[2];
+        g.v[s][0] = __builtin_bit_cast(T, w0);
+        g.v[s][1] = __builtin_bit_cast(T, w1);
+      }
+    }
+  };
+  auto add = [&](const Regs &g) {
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const uint32_t row = (k ? g.r[s] >> 16 : g.r[s]) & 0x7fffu;
+        if (lab == 1) { if (row == 12345 && g.v[s][k] == (T)77) ys[0] = (acc_t)g.v[s][k]; continue; }  // lab: stream only
+        atomicAdd(&ys[lab == 3 ? ((row & ~31u) | (uint32_t)(lane & 31)) : row], (acc_t)g.v[s][k]);  // lab 3: conflict-free by force (wrong sums)
+      }
+  };
+  constexpr int64_t kBatch = (int64_t)S * kStep, kStride = (int64_t)kPbWaves * kBatch;
+  int64_t cs = ps + (int64_t)wave * kBatch;
+  if (cs < pe) {
+    Regs ga, gb;
+    load(cs, ga);
+    for (;;) {
+      const int64_t c1 = cs + kStride;
+      load(c1, gb);
+      add(ga);
+      if (c1 >= pe) break;
+      const int64_t c2 = c1 + kStride;
+      load(c2, ga);
+      add(gb);
+      if (c2 >= pe) break;
+      cs = c2;
+    }
+  }
+  __syncthreads();
+  for (int j2 = tid; j2 < rows; j2 += kPbThreads) y[r0 + j2] = (T)ys[j2];
+}
+
 // ------------------------------------------------------------------------------------------------ folded layout
 // On a power-law matrix a heavy row has many entries in one column block: their products belong to one element of
 // y, and pass 1 can add them up before anything is written.  C3: a row of 1300 entries meets each of the 512 blocks
@@ -520,12 +609,6 @@ __device__ __forceinline__ P *pb_uniform_ptr(P *p) {  // p is the same in every 
 // that never changes, and an immediate: no vector instruction per load at all, three (and, bcnt + base, shift) per
 // store.  The descriptors are raw (stride 0) with the range check out of the way: every offset is in range by
 // construction of the layout.
-typedef unsigned int pb_u32x2 __attribute__((ext_vector_type(2)));
-constexpr int kPbRsrcFlags = 0x00020000;  // gfx9 raw buffer, 32-bit data format
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pb_rsrc(const void *base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7ffffffe, kPbRsrcFlags);
-}
 template <int AUX>
 __device__ __forceinline__ float pb_bload(__amdgpu_buffer_rsrc_t r, int off, const float *) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, AUX));
@@ -598,7 +681,6 @@ __device__ __forceinline__ T pb_run_sum32(T p, bool all_heads, uint32_t h, const
 // stream in flight, and a wavefront that asks for a step as 8 + 8 + 8 two- and four-byte loads cannot have more than
 // two steps outstanding (the 6-bit counter of outstanding vector-memory instructions also counts the 8 stores of a
 // step).  Five 16-byte loads per step leave room for a ring of three steps: two are in flight while one is summed.
-typedef unsigned int pb_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kPbChunk = 512;  // entries per chunk: 8 per lane
 
 template <class T>
@@ -1442,7 +1524,12 @@ int spmv_pb(futhark_context *ctx, const CsrBody<T> *a, const T *x, T *y) {
                        (const T *)a->pb_x, (const uint32_t *)a->pb_dgroup, a->pb_prod, (int)a->pb_w,
                        (int)((ctx->opt_ablate >> 2) & 3));
   SAMD_LAUNCH_CHECK(ctx);
-  hipLaunchKernelGGL((pb_pass2_kernel<T, 8>), dim3((unsigned)a->pb_np), dim3(kPbThreads), 0, ctx->stream,
+  if (a->pb_fold && !((ctx->opt_ablate >> 29) & 1))  // (bit 29: the one-product-per-lane kernel, for the tests)
+    hipLaunchKernelGGL((pb_pass2p_kernel<T>), dim3((unsigned)a->pb_np), dim3(kPbThreads), 0, ctx->stream,
+                       (const int64_t *)(a->pb_piece_ptr + a->pb_nb + 1), (const int64_t *)a->pb_panel_row,
+                       (const uint16_t *)a->pb_row16, (const T *)a->pb_prod, y, (int)(ctx->opt_ablate & 3));
+  else
+    hipLaunchKernelGGL((pb_pass2_kernel<T, 8>), dim3((unsigned)a->pb_np), dim3(kPbThreads), 0, ctx->stream,
                      (const int64_t *)(a->pb_piece_ptr + a->pb_nb + 1), (const int64_t *)a->pb_panel_row,
                      (const uint16_t *)a->pb_row16, (const T *)a->pb_prod, y, (int)(ctx->opt_ablate & 3),
                      ((ctx->opt_ablate & 3) == 2 || a->pb_fold) ? 0 : (ctx->opt_ablate >> 5) ? (int)(ctx->opt_ablate >> 5) : kPbFoldMax);
