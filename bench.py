@@ -513,7 +513,14 @@ def main():
         c3 = c3_leg(args, torch, dev, ctx)
         c4 = c4_leg(args, torch, dev, ctx)
     if not args.no_c5:
-        c5 = c5_leg(args, torch, dist, world, rank, dev, ctx, M)
+        # the headline above is measured by now: a failure in this leg (it is the one part of the N > 1 path no hardware
+        # has run before the driver does) is reported inside the line instead of costing the line
+        try:
+            c5 = c5_leg(args, torch, dist, world, rank, dev, ctx, M)
+        except Exception as e:     # noqa: BLE001 -- reported, not hidden: the c5 object then holds the error
+            import traceback
+            sys.stderr.write("c5 leg failed on rank %d:\n%s\n" % (rank, traceback.format_exc()))
+            c5 = {"error": "%s: %s" % (type(e).__name__, str(e)[:400]), "rank": rank}
 
     if rank == 0:
         ms = el / args.steps * 1e3
