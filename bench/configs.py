@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="any context option, key=value (kernel lab)")
     ap.add_argument("--asm-only", action="store_true", help="time the assembly only (kernel labs whose ablations leave a wrong record)")
+    ap.add_argument("--gap-ms", type=float, default=0.0, help="lab: synchronise and idle this long between the timed products (spmv_ms then includes it)")
     ap.add_argument("--compare", action="store_true", help="also time torch.sparse (rocSPARSE) CSR SpMV as a comparator")
     args = ap.parse_args()
     import torch
@@ -117,7 +118,12 @@ def main():
         M.sr.prepare(A, 1 << 20)   # "many products follow": whatever the record's path needs is built here, once
         ctx.sync()
         out["spmv_prepare_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
-        ms = timed(lambda: M.sr.smvm(A, x), args.steps, torch)
+        def product():
+            M.sr.smvm(A, x)
+            if args.gap_ms > 0:
+                torch.cuda.synchronize()
+                time.sleep(args.gap_ms * 1e-3)
+        ms = timed(product, args.steps, torch)
         # row offsets as the kernel reads them: 2 B (tile-relative u16) on the one-pass stream path of large records
         rb = 2 if (ctx.get_option("spmv_last_path") == 0 and nnz > 4096 * 1024 and not args.algo) else 8
         ib = ctx.get_option("spmv_last_col_bytes") if ctx.get_option("spmv_last_path") == 0 else 4
