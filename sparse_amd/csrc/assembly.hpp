@@ -486,30 +486,43 @@ __global__ __launch_bounds__(kBlock) void fold_emit_kernel(const K *__restrict__
   // wave 0 puts out the tile's count and requests its predecessors' status words; it looks at them after the fold
   unsigned long long lb_words = 0;
   if (tid < 64 && !(lab & 1)) lb_words = rl_publish(status, tile, total);
-  // ---- fold: a run's first pair adds the rest of the run, left to right.  The second pair of a run is the next
-  // lane's (same j): its value and the key behind it come by a lane shift, so the common run of two costs no load;
-  // longer runs, and runs that start in lane 63, go on from global memory.  (With a global load per step, nearly
-  // every one of the tile's rows of 64 pairs had some lane waiting for two dependent loads on a power-law input:
-  // 1 ms of the kernel's 2.8 on C3.)
+  // ---- fold: a run's first pair adds the rest of the run, left to right.  The 64 lanes of a wavefront hold 64
+  // consecutive pairs (same j), so a run goes on in the lanes to the right: its pairs come by lane shifts, one step
+  // for the whole wavefront per pair of the longest run in these 64 (no step at all where nothing repeats); only a run
+  // that reaches past lane 63 goes on from global memory.  (Round 2 took the second pair by a shift and the rest
+  // from memory: on a power-law input, whose hot cells repeat dozens of times, nearly every one of the tile's rows of
+  // 64 pairs then had a lane waiting for dependent loads -- 0.74 ms of the kernel's 2.65 on C3.)
 #pragma unroll
   for (int j = 0; j < kFoldItems; j++) {
-    const T vnext = wshfl_down(val[j], 1);
-    const K knext2 = wshfl_down(kn[j], 1);  // the key two places on
-    if (!(headmask & (1u << j)) || (lab & 2)) continue;
     const uint32_t i = base + j * 64;
-    if (i + 1 >= count || kn[j] != k[j]) continue;
-    auto src = [&](uint32_t q) -> int64_t { return (INDIRECT && perm) ? (int64_t)perm[q] : (int64_t)q; };
-    uint32_t q = i + 1;
-    if (lane < 63) {
-      val[j] = (T)(val[j] + vnext);
-      q = i + 2;
-      if (q >= count || knext2 != k[j]) continue;
+    bool go = (headmask & (1u << j)) && !(lab & 2) && i + 1 < count && kn[j] == k[j];
+    if (__ballot(go) == 0ull) continue;
+    T acc = val[j];
+    bool beyond = false;  // the run reaches past lane 63
+    for (int t = 1; __ballot(go) != 0ull; t++) {
+      const int srcl = lane + t;
+      const T vv = wshfl(val[j], srcl & 63);
+      const K kk = wshfl(k[j], srcl & 63);
+      if (go) {
+        if (srcl > 63) {
+          beyond = (uint64_t)i + (uint64_t)t < (uint64_t)count;  // (the pair in lane 63 was the run's: the next one may be too)
+          go = false;
+        } else if ((uint64_t)i + (uint64_t)t < (uint64_t)count && kk == k[j]) {
+          acc = (T)(acc + vv);
+        } else {
+          go = false;
+        }
+      }
     }
-    if ((uint64_t)i + kLongRun < (uint64_t)count && keys[(uint64_t)i + kLongRun] == k[j]) {  // more than kLongRun pairs
-      longmask |= 1u << j;
-      continue;
+    if (beyond) {
+      auto src = [&](uint32_t q) -> int64_t { return (INDIRECT && perm) ? (int64_t)perm[q] : (int64_t)q; };
+      if ((uint64_t)i + kLongRun < (uint64_t)count && keys[(uint64_t)i + kLongRun] == k[j]) {  // more than kLongRun pairs
+        longmask |= 1u << j;
+      } else {
+        for (uint32_t q = i + (uint32_t)(64 - lane); q < count && keys[q] == k[j]; q++) acc = (T)(acc + vals_in[src(q)]);
+      }
     }
-    for (; q < count && keys[q] == k[j]; q++) val[j] = (T)(val[j] + vals_in[src(q)]);
+    if (headmask & (1u << j)) val[j] = acc;  // (behind the loop: the lanes to the left read val[j] as it was loaded)
   }
   if (tid < 64) {  // wave 0: the tile's first output slot
     bool fail = false;
