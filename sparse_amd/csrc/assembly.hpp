@@ -693,8 +693,11 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
     Tmp<K> keys_b(ctx);
     Tmp<uint32_t> pay_a(ctx), pay_b(ctx), slot(ctx);
     Tmp<VB> val_a(ctx), val_b(ctx);
-    SAMD_TRY(keys_b.get(count));
-    SAMD_TRY(slot.get(count));
+    // 8-byte values that travel through the top-bit passes do so side by side with their keys, in buffers
+    // msd_sort_emit takes itself: no second key array and no value arrays then
+    const bool msd_pairs = msd_tb >= 0 && !indirect && sizeof(T) == 8 && sizeof(K) == 8 && ctx->opt_sort_pairs >= 0 &&
+                           ctx->opt_sort_algo == 0 && !ctx->sort_force_scan;
+    if (!msd_pairs) SAMD_TRY(keys_b.get(count));
     K *ks = nullptr;
     const uint32_t *perm = nullptr;
     const T *vs = nullptr;
@@ -721,8 +724,10 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
                                                        vals_in, count, msd_tb, end_bit, msd_ch, msd_small, minor_bits, b->col64,
                                                        b->vals, b->row_ptr, merged_dev, sort_err, oversize)));
         } else {
-          SAMD_TRY(val_a.get(count));
-          SAMD_TRY(val_b.get(count));
+          if (!msd_pairs) {
+            SAMD_TRY(val_a.get(count));
+            SAMD_TRY(val_b.get(count));
+          }
           if (c32)
             SAMD_TRY((msd_sort_emit<T, int32_t, false>(ctx, keys.p, keys_b.p, reinterpret_cast<const VB *>(vals_in),
                                                         val_a.p, val_b.p, (const T *)nullptr, count, msd_tb, end_bit,
@@ -907,6 +912,7 @@ int assemble_core(futhark_context *ctx, Tmp<K> &keys, int64_t count, int begin_b
       return 0;
     }
     // head flags -> slots; total -> host (the only synchronisation of an assembly)
+    SAMD_TRY(slot.get(count));
     uint32_t *slots = slot.p;
     SAMD_HIP(ctx, hipMemsetAsync(ctx->d_small, 0, sizeof(int64_t) * 2, ctx->stream));
     SAMD_TRY((device_scan<uint32_t, OpAdd, HeadFlagIn<K>, false>(ctx, HeadFlagIn<K>{ks}, count, 0u, OpAdd(), slots,

@@ -687,6 +687,7 @@ int sparse_amd_context_set_option(struct futhark_context *ctx, const char *key, 
   else if (!strcmp(key, "add_sort")) ctx->opt_add_sort = value;
   else if (!strcmp(key, "fold_emit")) ctx->opt_fold_emit = value;
   else if (!strcmp(key, "sort_msd_chunk")) ctx->opt_sort_msd_chunk = value;
+  else if (!strcmp(key, "sort_pairs")) ctx->opt_sort_pairs = value;
   else if (!strcmp(key, "spmv_reorder")) ctx->opt_spmv_reorder = value;
   else if (!strcmp(key, "spmv_col16")) ctx->opt_spmv_col16 = value;
   else if (!strcmp(key, "spmv_eager")) ctx->opt_spmv_eager = value;

@@ -137,6 +137,7 @@ struct futhark_context {
   bool sort_force_scan = false;    // set while an assembly is repeated after a look-back wait timed out: histogram + scan passes only
   int64_t opt_sort_msd = 0;        // assembly: 0 = top key bits by global passes + the rest in LDS when the sampled buckets are even, -1 never, T > 0 force T top bits
   int64_t opt_sort_msd_chunk = 0;  // lab/tests: nominal chunk length of the in-LDS sort
+  int64_t opt_sort_pairs = 0;      // assembly, 8-byte values carried through the top-bit passes: 0 = key and value side by side in one array, -1 = separate arrays
   int64_t last_long_runs = 0;      // runs of one coordinate the last assembly handed to fold_long_runs_kernel (tests read it back)
   int64_t last_sort_msd = 0;       // top bits the last assembly's sort gave to the global passes (0 = plain LSD, -1 = tried, did not fit, sorted again)
   int64_t opt_noalloc_scratch_bytes = 0;  // tests: treat the static scratch array as this small (0 = its real size)

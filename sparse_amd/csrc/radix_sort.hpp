@@ -227,7 +227,17 @@ constexpr int kRsGroup = 16;
 constexpr uint16_t kRsAggReady = 0x8000, kRsAggPoison = 0xffff;
 constexpr uint32_t kRsInclPoison = 0xffffffffu;
 
-template <class K, class P, int ITEMS, bool IOTA>
+// IN_AOS / OUT_AOS: key and payload side by side in ONE array of pairs (kin / kout point at it, pin / pout are not
+// used).  A digit's run then leaves the tile as one burst (16 pairs of 16 bytes: 256 B) instead of one of 128 B into
+// each of two arrays, most of which straddle two lines: 0.817 -> 0.748 ms per pass on C2's pairs.  Used between the
+// global passes of radix_sort_msd.hpp and into its in-LDS kernel, for 8-byte keys with 8-byte payloads.
+template <class K, class P>
+struct alignas((sizeof(K) + sizeof(P)) == 16 ? 16 : 8) RsPair {  // (only the 8 + 8 byte form is used; the others merely have to compile)
+  K k;
+  P p;
+};
+
+template <class K, class P, int ITEMS, bool IOTA, bool IN_AOS = false, bool OUT_AOS = false>
 __global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin, const P *__restrict__ pin,
                                                       K *__restrict__ kout, P *__restrict__ pout, uint32_t n,
                                                       int shift, uint32_t mask, const uint32_t *__restrict__ gbase,
@@ -268,8 +278,17 @@ __global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin,
   for (int k = 0; k < ITEMS; k++) {
     uint32_t i = base + k * 64;
     bool ok = i < n;
-    key[k] = ok ? kin[i] : (K)~(K)0;  // padding sorts to the very end of the tile
-    pay[k] = ok ? (IOTA ? (P)i : pin[i]) : (P)0;
+    if constexpr (IN_AOS) {
+      RsPair<K, P> pr;
+      pr.k = (K)~(K)0;
+      pr.p = (P)0;
+      if (ok) pr = reinterpret_cast<const RsPair<K, P> *>(kin)[i];
+      key[k] = pr.k;
+      pay[k] = pr.p;
+    } else {
+      key[k] = ok ? kin[i] : (K)~(K)0;  // padding sorts to the very end of the tile
+      pay[k] = ok ? (IOTA ? (P)i : pin[i]) : (P)0;
+    }
   }
   // ---- the tile's digit counts, and out with them (one add per run of equal neighbouring digits, see rs_hist_all)
 #pragma unroll
@@ -407,15 +426,26 @@ __global__ __launch_bounds__(kBlock) void rs_onesweep(const K *__restrict__ kin,
       const uint32_t d = (uint32_t)(kk >> shift) & mask;
       // lab 0x4000: contiguous stores (also forced by 0x2000 and 0x8000, whose offsets mean nothing)
       const uint32_t g = (lab & 0xe000) ? tile_base + i : goff[d] + i;
-      kout[g] = kk;
-      pout[g] = spay[i];
+      if constexpr (OUT_AOS) {
+        RsPair<K, P> pr;
+        pr.k = kk;
+        pr.p = spay[i];
+        reinterpret_cast<RsPair<K, P> *>(kout)[g] = pr;
+      } else {
+        kout[g] = kk;
+        pout[g] = spay[i];
+      }
     }
   }
 }
 
+// aos_a / aos_b (both or neither): buffers of n pairs each.  The passes then write pairs side by side into them in turn
+// (the first pass still reads keys_a / pay_in), keys_b / pay_a / pay_b are not touched, and *keys_out points at the
+// buffer of pairs that holds the result (*pay_out = nullptr).
 template <class K, class P>
 int radix_sort_pairs_onesweep(futhark_context *ctx, K *keys_a, K *keys_b, const P *pay_in, P *pay_a, P *pay_b,
-                              int64_t n, int begin_bit, int end_bit, K **keys_out, const P **pay_out, int *err) {
+                              int64_t n, int begin_bit, int end_bit, K **keys_out, const P **pay_out, int *err,
+                              RsPair<K, P> *aos_a = nullptr, RsPair<K, P> *aos_b = nullptr) {
   constexpr int ITEMS = RsCfg<K, P>::kItems;
   constexpr int TILE = RsCfg<K, P>::kTile;
   const uint32_t ntiles = (uint32_t)cdiv(n, TILE);
@@ -465,6 +495,26 @@ int radix_sort_pairs_onesweep(futhark_context *ctx, K *keys_a, K *keys_b, const 
     SAMD_HIP(ctx, hipMemsetAsync(incl.p, 0, sizeof(uint32_t) * (size_t)ngroups * kRsRadix, ctx->stream));
     const uint32_t *gbase = ghist.p + p * kRsRadix;
     uint32_t *ticket = ghist.p + passes * kRsRadix + 4 * p;
+    if (aos_a != nullptr) {
+      if constexpr (sizeof(K) == 8 && sizeof(P) == 8) {
+        RsPair<K, P> *dst = (p & 1) ? aos_b : aos_a;
+        const RsPair<K, P> *src = (p & 1) ? aos_a : aos_b;  // written by pass p - 1
+        if (p == 0)
+          hipLaunchKernelGGL((rs_onesweep<K, P, ITEMS, false, false, true>), dim3(ntiles), dim3(kBlock), 0, ctx->stream,
+                             (const K *)keys_a, pay_in, reinterpret_cast<K *>(dst), (P *)nullptr, (uint32_t)n, shift, mask, gbase,
+                             agg.p, incl.p, ticket, err, (int)ctx->opt_ablate);
+        else
+          hipLaunchKernelGGL((rs_onesweep<K, P, ITEMS, false, true, true>), dim3(ntiles), dim3(kBlock), 0, ctx->stream,
+                             reinterpret_cast<const K *>(src), (const P *)nullptr, reinterpret_cast<K *>(dst), (P *)nullptr,
+                             (uint32_t)n, shift, mask, gbase, agg.p, incl.p, ticket, err, (int)ctx->opt_ablate);
+        SAMD_LAUNCH_CHECK(ctx);
+        kin = reinterpret_cast<K *>(dst);
+        pin = nullptr;
+        continue;
+      } else {
+        return set_error(ctx, "internal: side-by-side pairs are for 8-byte keys and payloads");
+      }
+    }
     if (pin == nullptr)
       hipLaunchKernelGGL((rs_onesweep<K, P, ITEMS, true>), dim3(ntiles), dim3(kBlock), 0, ctx->stream, (const K *)kin,
                          pin, kout, pout, (uint32_t)n, shift, mask, gbase, agg.p, incl.p, ticket, err, (int)ctx->opt_ablate);
@@ -497,16 +547,23 @@ int radix_sort_pairs_onesweep(futhark_context *ctx, K *keys_a, K *keys_b, const 
 // On return *keys_out / *pay_out point at whichever buffers hold the result (pay_in itself
 // when no pass ran: nullptr then still means "identity").  sort_err: device int the one-sweep
 // variant raises if a look-back wait timed out (the caller reads it at its next synchronisation).
+// aos_a / aos_b / aos_used (all or none): see radix_sort_pairs_onesweep; *aos_used says whether the result is a buffer
+// of pairs (the histogram + scan variant and an empty bit range leave it false and use the separate arrays).
 template <class K, class P>
 int radix_sort_pairs(futhark_context *ctx, K *keys_a, K *keys_b, const P *pay_in, P *pay_a, P *pay_b, int64_t n,
-                     int begin_bit, int end_bit, K **keys_out, const P **pay_out, int *sort_err) {
+                     int begin_bit, int end_bit, K **keys_out, const P **pay_out, int *sort_err,
+                     RsPair<K, P> *aos_a = nullptr, RsPair<K, P> *aos_b = nullptr, bool *aos_used = nullptr) {
   constexpr int ITEMS = RsCfg<K, P>::kItems;
   constexpr int TILE = RsCfg<K, P>::kTile;
   if (n >= (int64_t)0xffff0000LL) return set_error(ctx, "sort: more than 2^32 entries on one device");
   const uint32_t ntiles = (uint32_t)cdiv(n, TILE);
-  if (ctx->opt_sort_algo == 0 && !ctx->sort_force_scan && n > 0 && end_bit > begin_bit && end_bit - begin_bit <= 8 * kRsMaxPasses)
+  if (aos_used) *aos_used = false;
+  if (ctx->opt_sort_algo == 0 && !ctx->sort_force_scan && n > 0 && end_bit > begin_bit && end_bit - begin_bit <= 8 * kRsMaxPasses) {
+    const bool aos = aos_used != nullptr && aos_a != nullptr && aos_b != nullptr && pay_in != nullptr;
+    if (aos) *aos_used = true;
     return radix_sort_pairs_onesweep<K, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, begin_bit, end_bit, keys_out,
-                                           pay_out, sort_err);
+                                           pay_out, sort_err, aos ? aos_a : nullptr, aos ? aos_b : nullptr);
+  }
   K *kin = keys_a, *kout = keys_b;
   const P *pin = pay_in;
   P *pout = pay_a, *pspare = pay_b;

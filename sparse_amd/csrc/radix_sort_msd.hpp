@@ -193,27 +193,28 @@ int msd_choose(futhark_context *ctx, const K *keys, int64_t count, int begin_bit
 
 // chunk c = [a[c], a[c+1]): a[c] = the first bucket boundary at or after c * ch
 template <class K>
-__global__ __launch_bounds__(kBlock) void msd_chunk_plan_kernel(const K *__restrict__ keys, uint32_t n, int tb,
+__global__ __launch_bounds__(kBlock) void msd_chunk_plan_kernel(const K *__restrict__ keys_base, uint32_t n, int tb,
                                                                 uint32_t ch, uint32_t nchunks,
-                                                                uint32_t *__restrict__ a) {
+                                                                uint32_t *__restrict__ a, int kstride) {  // kstride 2: keys inside pairs (RsPair)
+  auto keys = [&](uint64_t i) -> K { return keys_base[i * (uint64_t)kstride]; };
   const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
   if (c > nchunks) return;
   if (c == nchunks) { a[c] = n; return; }
   if (c == 0) { a[0] = 0; return; }
   const uint64_t s = (uint64_t)c * ch;  // < n
-  const K top0 = (K)(keys[s - 1] >> tb);
+  const K top0 = (K)(keys(s - 1) >> tb);
   // smallest i in [s, n] with i == n or top(keys[i]) != top0: gallop, then bisect
   uint64_t f = s - 1, t, step = 1;
   while (true) {
     const uint64_t probe = f + step;
     if (probe >= n) { t = n; break; }
-    if ((K)(keys[probe] >> tb) != top0) { t = probe; break; }
+    if ((K)(keys(probe) >> tb) != top0) { t = probe; break; }
     f = probe;
     step *= 2;
   }
   while (t - f > 1) {
     const uint64_t mid = f + (t - f) / 2;
-    if ((K)(keys[mid] >> tb) != top0) t = mid; else f = mid;
+    if ((K)(keys(mid) >> tb) != top0) t = mid; else f = mid;
   }
   a[c] = (uint32_t)t;
 }
@@ -313,7 +314,7 @@ __device__ __forceinline__ unsigned long long rl_lookback(unsigned long long *__
   return rl_finish(status, chunk, mine_count, w, fail);
 }
 
-template <class T, class I, bool INDIRECT, int ITEMS, int DB>
+template <class T, class I, bool INDIRECT, int ITEMS, int DB, bool AOS = false>  // AOS: kin points at pairs side by side (RsPair), pin is not used
 __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
     const uint64_t *__restrict__ kin, const typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *__restrict__ pin,
     const T *__restrict__ vals_src, const uint32_t *__restrict__ chunk_a, const uint32_t *__restrict__ nchunks_dev, int tb,
@@ -376,8 +377,14 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
   for (int k = 0; k < ITEMS; k++) {
     const uint32_t i = (uint32_t)k * kBlock + tid;
     if (k < R && i < L) {
-      scomp[rl_pad(i)] = kin[a + i];
-      spay[rl_pad(i)] = pin[a + i];
+      if constexpr (AOS) {
+        const RsPair<uint64_t, P> pr = reinterpret_cast<const RsPair<uint64_t, P> *>(kin)[a + i];
+        scomp[rl_pad(i)] = pr.k;
+        spay[rl_pad(i)] = pr.p;
+      } else {
+        scomp[rl_pad(i)] = kin[a + i];
+        spay[rl_pad(i)] = pin[a + i];
+      }
     }
   }
   __syncthreads();
@@ -623,8 +630,19 @@ int msd_sort_emit(futhark_context *ctx, uint64_t *keys_a, uint64_t *keys_b,
   typedef typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type P;
   uint64_t *ks = nullptr;
   const P *ps = nullptr;
-  SAMD_TRY((radix_sort_pairs<uint64_t, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, tb, end_bit, &ks, &ps, sort_err)));
-  if (ps == nullptr || ps == pay_in) return set_error(ctx, "internal: msd sort without a global pass");
+  // 8-byte values that travel with their keys: the passes write key and value side by side (radix_sort.hpp: RsPair)
+  constexpr bool kPairs = !INDIRECT && sizeof(P) == 8;
+  Tmp<RsPair<uint64_t, P>> aos_a(ctx), aos_b(ctx);
+  bool aos = false;
+  if (kPairs && ctx->opt_sort_pairs >= 0) {
+    SAMD_TRY(aos_a.get(n));
+    if (end_bit - tb > 8) SAMD_TRY(aos_b.get(n));  // (one pass writes only the first)
+    SAMD_TRY((radix_sort_pairs<uint64_t, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, tb, end_bit, &ks, &ps, sort_err,
+                                            aos_a.p, aos_b.p ? aos_b.p : aos_a.p, &aos)));
+  } else {
+    SAMD_TRY((radix_sort_pairs<uint64_t, P>(ctx, keys_a, keys_b, pay_in, pay_a, pay_b, n, tb, end_bit, &ks, &ps, sort_err)));
+  }
+  if (!aos && (ps == nullptr || ps == pay_in)) return set_error(ctx, "internal: msd sort without a global pass");
   const uint32_t nchunks = (uint32_t)cdiv(n, (int64_t)ch);  // nominal; the ones that hold nothing drop out below
   Tmp<uint32_t> ca(ctx), place(ctx), cb(ctx);
   Tmp<unsigned long long> status(ctx);
@@ -636,7 +654,7 @@ int msd_sort_emit(futhark_context *ctx, uint64_t *keys_a, uint64_t *keys_b,
   SAMD_HIP(ctx, hipMemsetAsync(ticket, 0, sizeof(uint32_t), ctx->stream));
   SAMD_HIP(ctx, hipMemsetAsync(status.p, 0, sizeof(unsigned long long) * (size_t)nchunks, ctx->stream));
   hipLaunchKernelGGL((msd_chunk_plan_kernel<uint64_t>), dim3((unsigned)cdiv((int64_t)nchunks + 1, kBlock)), dim3(kBlock), 0,
-                     ctx->stream, (const uint64_t *)ks, (uint32_t)n, tb, ch, nchunks, ca.p);
+                     ctx->stream, (const uint64_t *)ks, (uint32_t)n, tb, ch, nchunks, ca.p, aos ? 2 : 1);
   SAMD_LAUNCH_CHECK(ctx);
   // place[c] = chunks kept before c; place[nchunks] = chunks kept
   SAMD_TRY((device_scan<uint32_t, OpAdd, ChunkHoldsIn, true>(ctx, ChunkHoldsIn{ca.p}, nchunks, 0u, OpAdd(), place.p,
@@ -645,16 +663,17 @@ int msd_sort_emit(futhark_context *ctx, uint64_t *keys_a, uint64_t *keys_b,
                      ctx->stream, (const uint32_t *)ca.p, nchunks, (const uint32_t *)place.p, (uint32_t)n, cb.p);
   SAMD_LAUNCH_CHECK(ctx);
   const uint32_t *kept = place.p + nchunks;
-  if (small)
-    hipLaunchKernelGGL((rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItemsSmall, kRlDigitBits>), dim3(nchunks),
-                       dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)cb.p, kept, tb,
-                       minor_bits, col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0, status.p, ticket, merged_out,
-                       oversize, sort_err, (int)ctx->opt_ablate);
-  else
-    hipLaunchKernelGGL((rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItems, kRlDigitBits>), dim3(nchunks),
-                       dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src, (const uint32_t *)cb.p, kept, tb,
-                       minor_bits, col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0, status.p, ticket, merged_out,
-                       oversize, sort_err, (int)ctx->opt_ablate);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(nchunks), dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src,
+                       (const uint32_t *)cb.p, kept, tb, minor_bits, col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0,
+                       status.p, ticket, merged_out, oversize, sort_err, (int)ctx->opt_ablate);
+  };
+  if constexpr (kPairs) {
+    if (aos && small) launch(rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItemsSmall, kRlDigitBits, true>);
+    else if (aos) launch(rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItems, kRlDigitBits, true>);
+  }
+  if (!aos && small) launch(rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItemsSmall, kRlDigitBits, false>);
+  else if (!aos) launch(rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItems, kRlDigitBits, false>);
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
 }
