@@ -215,12 +215,14 @@ def test_sparse_one_coordinate_repeated_ten_million_times(ctx, dtype):
     assert ms < 50, "assembly of 1e7 equal coordinates took %.1f ms" % ms
 
 
-@pytest.mark.parametrize("dtype,indirect", [("f64", 1), ("f64", -1), ("f32", 0), ("i32", 0)])
+@pytest.mark.parametrize("dtype,indirect,pairs", [("f64", 1, 0), ("f64", -1, 0), ("f64", -1, -1), ("f32", 0, 0), ("i32", 0, 0)])
 @pytest.mark.parametrize("top,chunk", [(4, 0), (8, 700), (12, 0), (16, 2048), (20, 300), (32, 1000)])
-def test_sparse_top_bits_by_global_passes_rest_in_lds(ctx, dtype, indirect, top, chunk):
+def test_sparse_top_bits_by_global_passes_rest_in_lds(ctx, dtype, indirect, pairs, top, chunk):
     """radix_sort_msd.hpp, forced (option sort_msd = number of top key bits) on inputs the oracle can follow:
     buckets of thousands of triples down to single ones, chunks cut at bucket boundaries, one or two ordinal
-    passes, and buckets that do not fit a workgroup (top = 4: sixteen buckets of ~19 K): sorted again without it."""
+    passes, and buckets that do not fit a workgroup (top = 4: sixteen buckets of ~19 K): sorted again without it.
+    8-byte values that travel with their keys do so side by side with them (one array of pairs, option sort_pairs 0)
+    or in an array of their own (-1)."""
     n, m, k = 100000, 100000, 300000                      # 34 key bits
     r, c, v = random_coo(n, m, k, dtype, seed=top * 31 + chunk, dup_frac=0.2)
     O, M = Oracle(dtype), mk(ctx, dtype)
@@ -228,6 +230,7 @@ def test_sparse_top_bits_by_global_passes_rest_in_lds(ctx, dtype, indirect, top,
     ctx.set_option("sort_msd", top)
     ctx.set_option("sort_msd_chunk", chunk)
     ctx.set_option("sort_indirect", indirect)
+    ctx.set_option("sort_pairs", pairs)
     try:
         assert_same_record(M.sr.sparse(n, m, (r, c, v)), want)
         assert ctx.get_option("sort_last_msd") == (-1 if top == 4 else top)
@@ -252,6 +255,7 @@ def test_sparse_top_bits_by_global_passes_rest_in_lds(ctx, dtype, indirect, top,
         ctx.set_option("sort_msd", 0)
         ctx.set_option("sort_msd_chunk", 0)
         ctx.set_option("sort_indirect", 0)
+        ctx.set_option("sort_pairs", 0)
 
 
 def test_sparse_is_sorted_again_without_look_back_after_a_timed_out_wait(ctx):
