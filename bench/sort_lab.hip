@@ -1,7 +1,7 @@
 // sort_lab.hip -- the assembly's radix sort beside rocPRIM's on the same keys (calibration only;
 // rocPRIM is a comparator here, the library does not use it).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 bench/sort_lab.hip -o bench/sort_lab
-//   bench/sort_lab [count] [key_bits] [rounds]
+//   bench/sort_lab [count] [key_bits] [rounds] [ablate]
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -43,8 +43,9 @@ __global__ void check_sorted(const K *k, const uint32_t *p, const K *orig, uint3
 }
 
 template <class K>
-void run(int64_t n, int bits, int rounds) {
+void run(int64_t n, int bits, int rounds, long ablate) {
   futhark_context ctx;
+  ctx.opt_ablate = ablate;
   CK(hipStreamCreate(&ctx.stream));
   ctx.own_stream = ctx.stream;
   CK(hipHostMalloc((void **)&ctx.h_small, 128));
@@ -138,7 +139,8 @@ int main(int argc, char **argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 83869696;
   const int bits = argc > 2 ? atoi(argv[2]) : 48;
   const int rounds = argc > 3 ? atoi(argv[3]) : 5;
-  if (bits <= 32) run<uint32_t>(n, bits, rounds);
-  else run<uint64_t>(n, bits, rounds);
+  const long ablate = argc > 4 ? atol(argv[4]) : 0;  // the library's lab switches (0x10000: tiles in ticket order)
+  if (bits <= 32) run<uint32_t>(n, bits, rounds, ablate);
+  else run<uint64_t>(n, bits, rounds, ablate);
   return 0;
 }
