@@ -468,6 +468,15 @@ def test_smvm_two_pass_panels(ctx, dtype, geom, fold):
             ctx.set_option("spmv_pb_xcopy", 1)          # x copied into block order first (what an x that is not
             close(M.sr.smvm(A, x2), O.sr_smvm(Ao, x2), dtype)   # 16-byte aligned gets) instead of gathered by pass 1
             ctx.set_option("spmv_pb_xcopy", 0)
+            # an x that really is not 16-byte aligned (a view one element into a device buffer): pass 1's wide
+            # loads cannot gather from it, the library copies it into block order by itself
+            import torch
+            tdt = {"f64": torch.float64, "f32": torch.float32, "i32": torch.int32}[dtype]
+            buf = torch.zeros(m + 1, dtype=tdt, device="cuda")
+            buf[1:] = torch.as_tensor(np.asarray(x2), dtype=tdt, device="cuda")
+            xv = buf[1:]
+            assert xv.data_ptr() % 16 != 0
+            close(M.sr.smvm(A, ctx.array(xv, dtype)), O.sr_smvm(Ao, x2), dtype)
             assert_same_record(A, Ao)
     finally:
         for k in ("spmv_pb", "spmv_pb_rows", "spmv_pb_lines", "spmv_pb_entries", "spmv_pb_fold", "spmv_pb_deal", "spmv_pb_xcopy"):
