@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
     int minor_bits,
     I *__restrict__ col_out, T *__restrict__ vals_out, int64_t *__restrict__ row_ptr, int row_atomic,
     unsigned long long *__restrict__ status, uint32_t *__restrict__ ticket, unsigned long long *__restrict__ merged_out,
-    int *__restrict__ oversize, int *__restrict__ err, int lab) {
+    int *__restrict__ oversize, int *__restrict__ err, int lab, unsigned long long *__restrict__ rows_seen) {  // rows_seen (may be null; kSkipCounters counters of scan.hpp): += rows that end in this chunk
   typedef typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type P;
   constexpr int CAP = kBlock * ITEMS;
   static_assert(CAP <= (1 << kRlTagBits), "position tag too narrow");
@@ -570,6 +570,10 @@ __global__ __launch_bounds__(kBlock) void rs_local_sort_emit(
       }
     }
   }
+  if (rows_seen != nullptr) {  // (rows lie inside one chunk when this is asked for: every row is counted once)
+    const uint32_t ends = wave_reduce((uint32_t)__popc(endmask), OpAdd());
+    if ((tid & 63) == 0 && ends) atomicAdd(rows_seen + ((chunk & (kSkipCounters - 1)) * kSkipStride), (unsigned long long)ends);
+  }
   if (tid < 64) {  // wave 0: the chunk's first output slot
     bool fail = false;
     const unsigned long long off = (lab & 0x400) ? (unsigned long long)a : rl_finish(status, chunk, U, lb_words, &fail);
@@ -626,7 +630,8 @@ int msd_sort_emit(futhark_context *ctx, uint64_t *keys_a, uint64_t *keys_b,
                   typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *pay_a,
                   typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type *pay_b,
                   const T *vals_src, int64_t n, int tb, int end_bit, uint32_t ch, bool small, int minor_bits, I *col_out, T *vals_out,
-                  int64_t *row_ptr, unsigned long long *merged_out, int *sort_err, int *oversize) {
+                  int64_t *row_ptr, unsigned long long *merged_out, int *sort_err, int *oversize,
+                  unsigned long long *rows_seen = nullptr) {  // rows_seen: zeroed by the caller; receives the number of rows that hold something (only when every row lies inside one bucket)
   typedef typename std::conditional<INDIRECT, uint32_t, typename RlBits<T>::type>::type P;
   uint64_t *ks = nullptr;
   const P *ps = nullptr;
@@ -666,7 +671,8 @@ int msd_sort_emit(futhark_context *ctx, uint64_t *keys_a, uint64_t *keys_b,
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(nchunks), dim3(kBlock), 0, ctx->stream, (const uint64_t *)ks, ps, vals_src,
                        (const uint32_t *)cb.p, kept, tb, minor_bits, col_out, vals_out, row_ptr, tb < minor_bits ? 1 : 0,
-                       status.p, ticket, merged_out, oversize, sort_err, (int)ctx->opt_ablate);
+                       status.p, ticket, merged_out, oversize, sort_err, (int)ctx->opt_ablate,
+                       tb < minor_bits ? (unsigned long long *)nullptr : rows_seen);
   };
   if constexpr (kPairs) {
     if (aos && small) launch(rs_local_sort_emit<T, I, INDIRECT, RlEmitCfg<T>::kItemsSmall, kRlDigitBits, true>);

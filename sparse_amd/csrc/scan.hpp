@@ -131,9 +131,29 @@ __device__ __forceinline__ V block_exclusive_add(V x, V *sh, V &total) {
   return off + inc - x;
 }
 
+// skip (optional, all three kernels of a scan alike): kSkipCounters counters, one per 128-byte line (kernels that
+// count into one address from every workgroup queue up at that address: 262 K adds cost the in-LDS sort 2 ms on C2).
+// Their sum == skip_when means the caller's array needs no scan -- the kernels leave at once (the row ends of an
+// assembly in which every row holds something are final as written).
+constexpr int kSkipCounters = 64, kSkipStride = 16;  // in 8-byte words
+__device__ __forceinline__ bool scan_skips(const unsigned long long *skip, unsigned long long skip_when) {
+  if (skip == nullptr) return false;  // uniform
+  __shared__ int s_skip;
+  if (threadIdx.x < 64) {
+    unsigned long long v = threadIdx.x < kSkipCounters ? skip[threadIdx.x * kSkipStride] : 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (threadIdx.x == 0) s_skip = v == skip_when ? 1 : 0;
+  }
+  __syncthreads();
+  return s_skip != 0;
+}
 template <class V, class Op, class In>
-__global__ __launch_bounds__(kBlock) void scan_reduce_kernel(In in, int64_t n, V ident, Op op, V *sums) {
+__global__ __launch_bounds__(kBlock) void scan_reduce_kernel(In in, int64_t n, V ident, Op op, V *sums,
+                                                            const unsigned long long *skip = nullptr,
+                                                            unsigned long long skip_when = 0) {
   __shared__ V sh[kWaves];
+  if (scan_skips(skip, skip_when)) return;
   const int64_t base = (int64_t)blockIdx.x * kScanTile;
   V acc = ident;
 #pragma unroll
@@ -155,8 +175,11 @@ __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(In in, int64_t n, V
 // the block's first barrier and written only after it.
 template <class V, class Op, class In, bool EXCLUSIVE_ADD>
 __global__ __launch_bounds__(kBlock) void scan_apply_kernel(In in, int64_t n, V ident, Op op,
-                                                           const V *sums_incl, V *out, V *d_total) {
+                                                           const V *sums_incl, V *out, V *d_total,
+                                                           const unsigned long long *skip = nullptr,
+                                                           unsigned long long skip_when = 0) {
   __shared__ V sh[kWaves];
+  if (scan_skips(skip, skip_when)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)wave * (kScanItems * 64) + lane;
   V x[kScanItems], v[kScanItems];
@@ -185,7 +208,8 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(In in, int64_t n, V 
 //   EXCLUSIVE_ADD=true : exclusive prefix sum (op must be OpAdd).
 // d_total (optional, device) receives the reduction of all n inputs.
 template <class V, class Op, class In, bool EXCLUSIVE_ADD>
-int device_scan(futhark_context *ctx, In in, int64_t n, V ident, Op op, V *out, V *d_total) {
+int device_scan(futhark_context *ctx, In in, int64_t n, V ident, Op op, V *out, V *d_total,
+                const unsigned long long *skip = nullptr, unsigned long long skip_when = 0) {
   if (n <= 0) {
     if (d_total) SAMD_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(V), ctx->stream));  // ident is 0 for every use here
     return 0;
@@ -194,18 +218,19 @@ int device_scan(futhark_context *ctx, In in, int64_t n, V ident, Op op, V *out, 
   if (nblocks > 0x7fffffffLL) return set_error(ctx, "scan: input too large");
   if (nblocks == 1) {
     hipLaunchKernelGGL((scan_apply_kernel<V, Op, In, EXCLUSIVE_ADD>), dim3(1), dim3(kBlock), 0, ctx->stream, in, n,
-                       ident, op, (const V *)nullptr, out, d_total);
+                       ident, op, (const V *)nullptr, out, d_total, skip, skip_when);
     SAMD_LAUNCH_CHECK(ctx);
     return 0;
   }
   Tmp<V> sums(ctx);
   SAMD_TRY(sums.get(nblocks));
   hipLaunchKernelGGL((scan_reduce_kernel<V, Op, In>), dim3((unsigned)nblocks), dim3(kBlock), 0, ctx->stream, in, n,
-                     ident, op, sums.p);
+                     ident, op, sums.p, skip, skip_when);
   SAMD_LAUNCH_CHECK(ctx);
-  SAMD_TRY((device_scan<V, Op, PtrIn<V>, false>(ctx, PtrIn<V>{sums.p}, nblocks, ident, op, sums.p, (V *)nullptr)));
+  SAMD_TRY((device_scan<V, Op, PtrIn<V>, false>(ctx, PtrIn<V>{sums.p}, nblocks, ident, op, sums.p, (V *)nullptr, skip,
+                                                skip_when)));
   hipLaunchKernelGGL((scan_apply_kernel<V, Op, In, EXCLUSIVE_ADD>), dim3((unsigned)nblocks), dim3(kBlock), 0,
-                     ctx->stream, in, n, ident, op, (const V *)sums.p, out, d_total);
+                     ctx->stream, in, n, ident, op, (const V *)sums.p, out, d_total, skip, skip_when);
   SAMD_LAUNCH_CHECK(ctx);
   return 0;
 }
