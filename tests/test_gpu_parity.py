@@ -258,6 +258,33 @@ def test_sparse_top_bits_by_global_passes_rest_in_lds(ctx, dtype, indirect, pair
         ctx.set_option("sort_pairs", 0)
 
 
+@pytest.mark.parametrize("top", [0, 16])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_sparse_row_ends_with_and_without_empty_rows(ctx, dtype, top):
+    """The emission kernels count the rows that hold something; when that is every row, the max-scan that fills the
+    empty rows' ends in is skipped.  Every row occupied (skipped), one row empty in the middle / at the start / at the
+    end (not skipped) -- with duplicates, so that the number of triples says nothing -- after the LSD sort (top = 0)
+    and through the in-LDS emission (top = 16)."""
+    n, m = 5000, 3000
+    O, M = Oracle(dtype), mk(ctx, dtype)
+    base_r = np.arange(n, dtype=np.int64)
+    extra_r = (synth.splitmix64(3, np.arange(20000, dtype=np.uint64)) % np.uint64(n)).astype(np.int64)
+    ctx.set_option("sort_msd", top)
+    try:
+        for hole in (None, 2500, 0, n - 1):
+            r = np.concatenate([base_r, extra_r, extra_r[:3000]])            # the last 3000 repeat coordinates
+            c = (synth.splitmix64(4, np.arange(len(r), dtype=np.uint64)) % np.uint64(m)).astype(np.int64)
+            c[-3000:] = c[n:n + 3000]
+            if hole is not None:
+                keep = r != hole
+                r, c = r[keep], c[keep]
+            v = synth.uniform_values(5, len(r), dtype)
+            A = M.sr.sparse(n, m, (r, c, v))
+            assert_same_record(A, O.sr_sparse(n, m, r, c, v))
+    finally:
+        ctx.set_option("sort_msd", 0)
+
+
 def test_sparse_is_sorted_again_without_look_back_after_a_timed_out_wait(ctx):
     """A look-back wait that runs into its limit (GPU shared or preempted for seconds) no longer fails the assembly:
     it is repeated with histogram + scan passes, which wait for nothing.  Injected: option sort_inject."""
