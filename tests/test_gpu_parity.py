@@ -258,13 +258,14 @@ def test_sparse_top_bits_by_global_passes_rest_in_lds(ctx, dtype, indirect, pair
         ctx.set_option("sort_pairs", 0)
 
 
-@pytest.mark.parametrize("top", [0, 16])
+@pytest.mark.parametrize("top", [0, 8, 16])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_sparse_row_ends_with_and_without_empty_rows(ctx, dtype, top):
     """The emission kernels count the rows that hold something; when that is every row, the max-scan that fills the
     empty rows' ends in is skipped.  Every row occupied (skipped), one row empty in the middle / at the start / at the
     end (not skipped) -- with duplicates, so that the number of triples says nothing -- after the LSD sort (top = 0)
-    and through the in-LDS emission (top = 16)."""
+    and through the in-LDS emission (top = 8: buckets of whole rows, counted; top = 16: rows cut across buckets, not
+    counted, always scanned)."""
     n, m = 5000, 3000
     O, M = Oracle(dtype), mk(ctx, dtype)
     base_r = np.arange(n, dtype=np.int64)
